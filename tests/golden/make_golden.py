@@ -1,0 +1,400 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REAL reference (read-only, /root/reference) on CPU.
+
+Container-only tool.  It imports the reference's own
+``Experimental_root/archs/bsvd_arch.py`` (and the TSN/WNet twin for the blind case)
+through a small shim and writes input/output vectors as ``.npz`` fixtures next to
+this file.  Nothing of the reference (source, bytecode) is copied: fixtures hold
+only seeded inputs and the arrays the reference computed from them.  Weights are not
+stored either; they are regenerated from ``seeded.seeded_state`` and guarded by a
+SHA-256 digest.
+
+Shim: ``basicsr`` cannot be imported as a package here (needs a
+generated version.py, cv2, torchvision), so only ``basicsr/utils/registry.py`` is
+loaded by path; the hard-coded ``.cuda()`` / ``device='cuda'`` sites
+(bsvd_arch.py:94,104,520) are patched to stay on CPU.
+
+Usage:  python tests/golden/make_golden.py        (re-creates every fixture)
+"""
+import importlib.util
+import os
+import sys
+import types
+from collections import OrderedDict
+
+sys.dont_write_bytecode = True
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from seeded import seeded_state, state_digest, seeded_clip  # noqa: E402
+
+REF = os.environ.get("BSVD_REFERENCE", "/root/reference")
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def import_reference():
+    """Returns a namespace with the reference's BSVD / DenBlock / ... classes, CPU-patched."""
+    if "ref_bsvd_arch" in sys.modules:
+        return sys.modules["ref_bsvd_arch"]
+    for pkg in ("basicsr", "basicsr.utils", "Experimental_root", "Experimental_root.models",
+                "Experimental_root.archs"):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = []
+            sys.modules[pkg] = m
+    _load("basicsr.utils.registry", os.path.join(REF, "BasicSR/basicsr/utils/registry.py"))
+    # CPU patches for the hard-coded device
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    _zeros = torch.zeros
+
+    def zeros_cpu(*a, **k):
+        k.pop("device", None)
+        return _zeros(*a, **k)
+
+    torch.zeros = zeros_cpu
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.empty_cache = lambda *a, **k: None
+    return _load("ref_bsvd_arch", os.path.join(REF, "Experimental_root/archs/bsvd_arch.py"))
+
+
+def import_reference_tsn():
+    """The training-time twin (TSN/WNet/TemporalShift), used for the blind (WNet-semantics) golden."""
+    import_reference()
+    if "Experimental_root.archs.tsm_arch" in sys.modules:
+        return (sys.modules["Experimental_root.archs.tsm_arch"],
+                sys.modules["Experimental_root.models.global_queue_buffer"])
+    gq = _load("Experimental_root.models.global_queue_buffer",
+               os.path.join(REF, "Experimental_root/models/global_queue_buffer.py"))
+    sys.modules["Experimental_root.models"].global_queue_buffer = gq
+    for pkg in ("Experimental_root.archs.archs_2d", "Experimental_root.archs.temporal_shift_ops"):
+        m = types.ModuleType(pkg)
+        m.__path__ = []
+        sys.modules[pkg] = m
+    _load("Experimental_root.archs.archs_2d.wnet_models",
+          os.path.join(REF, "Experimental_root/archs/archs_2d/wnet_models.py"))
+    _load("Experimental_root.archs.temporal_shift_ops.temporal_shift",
+          os.path.join(REF, "Experimental_root/archs/temporal_shift_ops/temporal_shift.py"))
+    tsm = _load("Experimental_root.archs.tsm_arch", os.path.join(REF, "Experimental_root/archs/tsm_arch.py"))
+    return tsm, gq
+
+
+def import_reference_callers():
+    """validation_seq_infer.denoise_seq and DenoisingModel.padding_input/crop_output (stubbed imports)."""
+    import_reference()
+    if "Experimental_root.models.global_queue_buffer" in sys.modules:
+        gq = sys.modules["Experimental_root.models.global_queue_buffer"]
+    else:
+        gq = _load("Experimental_root.models.global_queue_buffer",
+                   os.path.join(REF, "Experimental_root/models/global_queue_buffer.py"))
+    sys.modules["Experimental_root.models"].global_queue_buffer = gq
+    vsi = _load("Experimental_root.models.validation_seq_infer",
+                os.path.join(REF, "Experimental_root/models/validation_seq_infer.py"))
+    stubs = {
+        "basicsr.archs": {"build_network": None},
+        "basicsr.losses": {"build_loss": None},
+        "basicsr.metrics": {"calculate_metric": None},
+        "basicsr.models": {},
+        "basicsr.models.base_model": {"BaseModel": object},
+    }
+    for name, attrs in stubs.items():
+        m = types.ModuleType(name)
+        m.__path__ = []
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+    u = sys.modules["basicsr.utils"]
+    u.get_root_logger = u.imwrite = u.tensor2img = None
+    if "tqdm" not in sys.modules:
+        import tqdm  # noqa: F401
+    dm = _load("Experimental_root.models.denoising_model",
+               os.path.join(REF, "Experimental_root/models/denoising_model.py"))
+    return vsi, dm
+
+
+def load_seeded(module, seed):
+    sd = module.state_dict()
+    st = seeded_state([(k, tuple(v.shape)) for k, v in sd.items()], seed)
+    module.load_state_dict(OrderedDict((k, torch.from_numpy(v)) for k, v in st.items()))
+    return st
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %-34s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def t2n(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- fixtures
+def g1_shiftconv(ref):
+    """ShiftConv channel routing + weight indexing (bsvd_arch.py:21-50)."""
+    for C, hw, seed in ((32, (12, 20), 101), (128, (6, 10), 102)):
+        m = ref.ShiftConv(C, C, 3, 1, 1, True)
+        st = load_seeded(m, seed)
+        rs = np.random.RandomState(seed + 1000)
+        fold = C // 8
+        left = rs.standard_normal((1, fold) + hw).astype(np.float32)
+        center = rs.standard_normal((1, C) + hw).astype(np.float32)
+        right = rs.standard_normal((1, C) + hw).astype(np.float32)
+        with torch.no_grad():
+            out = m(torch.from_numpy(left), torch.from_numpy(center), torch.from_numpy(right))
+        save("g1_shiftconv_c%d" % C, left=left, center=center, right=right, out=t2n(out),
+             seed=np.int64(seed), digest=np.array(state_digest(st)))
+
+
+def g2_bibuffer(ref):
+    """BiBufferConv start/steady/flush semantics (bsvd_arch.py:53-114): per-call outputs + None pattern."""
+    C, hw, seed = 32, (8, 12), 201
+    for T in (1, 2, 3, 5):
+        m = ref.BiBufferConv(C, C, 3, 1, 1, True)
+        st = load_seeded(m, seed)
+        rs = np.random.RandomState(seed + T)
+        xs = rs.standard_normal((T, 1, C) + hw).astype(np.float32)
+        calls = [torch.from_numpy(x) for x in xs] + [None, None]
+        outs, is_none = [], []
+        with torch.no_grad():
+            for x in calls:
+                y = m(x)
+                is_none.append(y is None)
+                if y is not None:
+                    outs.append(t2n(y))
+        save("g2_bibuffer_T%d" % T, x=xs, out=np.stack(outs, 0), is_none=np.array(is_none),
+             seed=np.int64(seed), digest=np.array(state_digest(st)))
+
+
+def _stream_block(block, frames, flush):
+    outs = []
+    with torch.no_grad():
+        for x in list(frames) + [None] * flush:
+            y = block(x)
+            if y is not None:
+                outs.append(y.clone())
+    return outs
+
+
+def g3_denblock(ref):
+    """DenBlock U-Net wiring, PixelShuffle order, skip alignment, residual (bsvd_arch.py:325-414).
+
+    Taps are captured with forward hooks on the sub-blocks (clone before the in-place residual)."""
+    chns, T, hw, seed = [32, 64, 128], 5, (8, 12), 301
+    for tag, in_ch, out_ch in (("a", 4, 32), ("b", 32, 3)):
+        blk = ref.DenBlock(chns=chns, out_ch=out_ch, in_ch=in_ch, shift_input=False, norm="none",
+                           act="relu6", interm_ch=32, blind=False)
+        st = load_seeded(blk, seed)
+        taps = {k: [] for k in ("x0", "x1", "x2", "u2", "u1", "o")}
+
+        def hook(name):
+            def fn(mod, inp, out):
+                if out is not None:
+                    taps[name].append(t2n(out.clone()))
+            return fn
+
+        blk.inc.register_forward_hook(hook("x0"))
+        blk.downc0.register_forward_hook(hook("x1"))
+        blk.downc1.register_forward_hook(hook("x2"))
+        blk.upc2.register_forward_hook(hook("u2"))
+        blk.upc1.register_forward_hook(hook("u1"))
+        blk.outc.register_forward_hook(hook("o"))
+        rs = np.random.RandomState(seed + 7)
+        x = rs.standard_normal((T, in_ch) + hw).astype(np.float32)
+        outs = _stream_block(blk, [torch.from_numpy(x[i:i + 1]) for i in range(T)], flush=9)
+        assert len(outs) == T, len(outs)
+        arrays = {k: np.concatenate(v, 0) for k, v in taps.items()}
+        save("g3_denblock_" + tag, x=x, out=np.concatenate([t2n(o) for o in outs], 0),
+             seed=np.int64(seed), digest=np.array(state_digest(st)), **arrays)
+
+
+def g4_bsvd_small(ref):
+    """Whole streaming BSVD on a small net incl. stream-edge cases T=1,2,3 (bsvd_arch.py:490-552)."""
+    seed = 401
+    for T in (1, 2, 3, 7):
+        net = ref.BSVD(chns=[32, 64, 128], mid_ch=32, shift_input=False, in_ch=4, out_ch=3, norm="none",
+                       act="relu6", interm_ch=32, blind=False, pretrain_ckpt=None)
+        st = load_seeded(net, seed)
+        x = seeded_clip((1, T, 4, 16, 24), seed + T)
+        # instrument the call/None schedule (Appendix B of SURVEY)
+        calls = []
+        orig = net.feedin_one_element
+
+        def wrapped(v, _orig=orig):
+            y = _orig(v)
+            calls.append((v is None, y is None))
+            return y
+
+        net.feedin_one_element = wrapped
+        with torch.no_grad():
+            y = net(torch.from_numpy(x))
+            y2 = net(torch.from_numpy(x))  # state fully reset -> identical
+        assert torch.equal(y, y2)
+        save("g4_bsvd_small_T%d" % T, x=x, out=t2n(y), schedule=np.array(calls[:len(calls) // 2]),
+             seed=np.int64(seed), digest=np.array(state_digest(st)), shift_num=np.int64(net.shift_num))
+
+
+def g4b_bsvd_defaults(ref):
+    """Constructor defaults of the reference (mid_ch=3, interm_ch=30, act='relu') with norm='none':
+    odd channel counts (3, 30) and fold=4."""
+    seed = 451
+    net = ref.BSVD(norm="none", pretrain_ckpt=None)
+    st = load_seeded(net, seed)
+    x = seeded_clip((1, 4, 4, 16, 20), seed + 1, kind="sigma30")
+    with torch.no_grad():
+        y = net(torch.from_numpy(x[:, :, :3]), noise_map=torch.from_numpy(x[:, :, 3:4]))
+    save("g4b_bsvd_defaults", x=x, out=t2n(y), seed=np.int64(seed), digest=np.array(state_digest(st)))
+
+
+def g5_bsvd_c64(ref):
+    """The shipped config bsvd_c64 (options/test/bsvd_c64.yml:85-93): real channel counts, K up to 2304."""
+    seed = 501
+    for tag, shape, kind in (("a", (1, 5, 4, 32, 48), "randn"), ("b", (1, 3, 4, 64, 96), "sigma30"),
+                             ("c", (1, 2, 4, 20, 36), "sigma30")):
+        net = ref.BSVD(chns=[64, 128, 256], mid_ch=64, shift_input=False, in_ch=4, out_ch=3, norm="none",
+                       act="relu6", interm_ch=64, blind=False, pretrain_ckpt=None)
+        st = load_seeded(net, seed)
+        x = seeded_clip(shape, seed + len(tag) + shape[1], kind=kind)
+        taps = {}
+
+        def hook(name):
+            def fn(mod, inp, out):
+                if out is not None:
+                    taps.setdefault(name, []).append(t2n(out.clone()))
+            return fn
+
+        hs = []
+        if tag == "c":  # taps only on the smallest case (fixture size)
+            hs = [net.temp1.inc.register_forward_hook(hook("t1_x0")),
+                  net.temp1.downc1.register_forward_hook(hook("t1_x2")),
+                  net.temp1.register_forward_hook(hook("t1_out"))]
+        with torch.no_grad():
+            y = net(torch.from_numpy(x))
+        for h in hs:
+            h.remove()
+        arrays = {k: np.concatenate(v, 0) for k, v in taps.items()}
+        save("g5_bsvd_c64_" + tag, x=x, out=t2n(y), seed=np.int64(seed), digest=np.array(state_digest(st)),
+             **arrays)
+
+
+def g6_blind():
+    """Blind c64 with WNet semantics (only stage 0 blind) through the TSN whole-clip path
+    (tsm_arch.py:11, wnet_models.py:233, temporal_shift.py:53).  BSVD(blind=True) itself is broken in the
+    reference; the engine implements the WNet semantics."""
+    tsm, gq = import_reference_tsn()
+    seed = 601
+    net = tsm.TSN(num_segments=5, base_model="WNet_multistage", shift_type="TSM", shift_div=8,
+                  net2d_opt=dict(chns=[64, 128, 256], mid_ch=64, shift_input=False, stage_num=2, in_ch=4,
+                                 out_ch=3, norm="none", act="relu", interm_ch=30, blind=True))
+    net.eval()
+    st = load_seeded(net, seed)
+    x = seeded_clip((1, 5, 3, 32, 48), seed + 1, kind="sigma30")
+    gq._init(0)
+    gq.set_batch_index(0)
+    with torch.no_grad():
+        y = net(torch.from_numpy(x))
+    gq._clean()
+    keys = np.array(list(st.keys()))
+    shapes = np.array([",".join(map(str, v.shape)) for v in st.values()])
+    save("g6_blind_c64", x=x, out=t2n(y), seed=np.int64(seed), digest=np.array(state_digest(st)),
+         tsn_keys=keys, tsn_shapes=shapes)
+
+
+def g7_ckpt_keymap(ref):
+    """TSN-schema checkpoint -> BSVD key map (bsvd_arch.py:462-474 and the per-block load()s).
+    A TSN c64 state is saved to a temp .pth, loaded with the reference's BSVD.load, and the
+    resulting correspondence (which TSN tensor landed in which BSVD key) is recorded by value."""
+    import tempfile
+    tsm, gq = import_reference_tsn()
+    seed = 701
+    tsn = tsm.TSN(num_segments=5, base_model="WNet_multistage", shift_type="TSM", shift_div=8,
+                  net2d_opt=dict(chns=[64, 128, 256], mid_ch=64, shift_input=False, stage_num=2, in_ch=4,
+                                 out_ch=3, norm="none", act="relu6", interm_ch=64, blind=False))
+    st = load_seeded(tsn, seed)
+    net = ref.BSVD(chns=[64, 128, 256], mid_ch=64, shift_input=False, in_ch=4, out_ch=3, norm="none",
+                   act="relu6", interm_ch=64, blind=False, pretrain_ckpt=None)
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "tsn.pth")
+        torch.save({"params": OrderedDict(("module." + k, v) for k, v in tsn.state_dict().items())}, p)
+        net.load(p)
+    # identify by value (seeded tensors are all distinct)
+    fp = {}
+    for k, v in tsn.state_dict().items():
+        fp[(tuple(v.shape), float(v.flatten()[0]), float(v.flatten()[-1]))] = k
+    pairs = []
+    for k, v in net.state_dict().items():
+        src = fp[(tuple(v.shape), float(v.flatten()[0]), float(v.flatten()[-1]))]
+        pairs.append((src, k, ",".join(map(str, v.shape))))
+    # TSN whole-clip forward == BSVD streaming forward on the mapped weights
+    x = seeded_clip((1, 4, 4, 16, 24), seed + 1)
+    tsn.eval()
+    gq._init(0)
+    gq.set_batch_index(0)
+    with torch.no_grad():
+        y_tsn = tsn(torch.from_numpy(x))
+        y_bsvd = net(torch.from_numpy(x))
+    gq._clean()
+    print("   TSN clip vs BSVD stream max-abs: %.3e" % float((y_tsn - y_bsvd).abs().max()))
+    save("g7_ckpt_keymap", tsn_keys=np.array([p[0] for p in pairs]), bsvd_keys=np.array([p[1] for p in pairs]),
+         shapes=np.array([p[2] for p in pairs]), x=x, out_bsvd=t2n(y_bsvd), out_tsn=t2n(y_tsn),
+         seed=np.int64(seed), tsn_digest=np.array(state_digest(st)))
+
+
+def g8_pad_crop_clamp():
+    """Callers: DenoisingModel.padding_input / crop_output (denoising_model.py:133-168) and
+    denoise_seq/temp_denoise with temp_psz=-1 (validation_seq_infer.py:10-100)."""
+    vsi, dm = import_reference_callers()
+    lq = torch.arange(5 * 3 * 30 * 50, dtype=torch.float32).reshape(5, 3, 30, 50) / 1000.0
+    ns = types.SimpleNamespace(lq=lq)
+    padded, plist = dm.DenoisingModel.padding_input(ns, lq)
+    ns.output = padded[None].clone()
+    dm.DenoisingModel.crop_output(ns, plist)
+
+    class Dummy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+            self.seen = None
+
+        def forward(self, x, noise_map=None):
+            self.seen = (tuple(x.shape), None if noise_map is None else tuple(noise_map.shape),
+                         None if noise_map is None else float(noise_map.flatten()[0]))
+            return x * 3.0 - 1.0  # leaves [0,1] on purpose -> clamp visible
+
+    rs = np.random.RandomState(801)
+    seq = torch.from_numpy(rs.uniform(0, 1, (7, 3, 8, 8)).astype(np.float32))
+    nm = torch.full((7, 1, 8, 8), 30.0 / 255.0)
+    dummy = Dummy()
+    den = vsi.denoise_seq(seq, nm, -1, dummy)
+    save("g8_pad_crop_clamp", lq=t2n(lq), padded=t2n(padded), padding_list=np.array(plist),
+         cropped=t2n(ns.output), seq=t2n(seq), den=t2n(den), seen_x=np.array(dummy.seen[0]),
+         seen_nm=np.array(dummy.seen[1]), seen_sigma=np.float32(dummy.seen[2]))
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    ref = import_reference()
+    g1_shiftconv(ref)
+    g2_bibuffer(ref)
+    g3_denblock(ref)
+    g4_bsvd_small(ref)
+    g4b_bsvd_defaults(ref)
+    g5_bsvd_c64(ref)
+    g6_blind()
+    g7_ckpt_keymap(ref)
+    g8_pad_crop_clamp()
+
+
+if __name__ == "__main__":
+    main()
