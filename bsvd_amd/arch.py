@@ -1,0 +1,196 @@
+"""``BSVD`` -- the drop-in network class behind the reference's plug-in boundary.
+
+Same constructor, attributes, parameter names and call protocol as
+/root/reference/Experimental_root/archs/bsvd_arch.py:441-560 (``BSVD``), registered in ARCH_REGISTRY
+(bsvd_arch.py:440), so ``build_network({'type': 'BSVD', ...})`` / ``DenoisingModel`` / ``profile.py`` style
+drivers work unchanged -- but everything under ``forward`` runs as hand-written gfx950 kernels through
+the C ABI (include/bsvd_hip.h).  The module tree only HOLDS the parameters (so ``state_dict()``,
+``.to()``, ``.half()``, ``.parameters()`` behave as in the reference); it is never called layer by layer.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import checkpoint
+from .netspec import make_netspec
+from .registry import register_arch
+from .schedule import StreamPipeline, bsvd_clip
+
+
+class _Slots(nn.Module):
+    """Plain container whose children get the given names (mirrors the reference's attribute names)."""
+
+    def __init__(self, **children):
+        super().__init__()
+        for k, v in children.items():
+            self.add_module(k, v)
+
+
+def _conv(cin, cout, stride=1):
+    # parameter holder with nn.Conv2d's names/shapes/default bias init; weight re-initialised below
+    return nn.Conv2d(cin, cout, 3, stride=stride, padding=1, bias=True)
+
+
+def _mem(c):
+    return _Slots(c1=_Slots(op=_Slots(conv=_conv(c, c))), c2=_Slots(op=_Slots(conv=_conv(c, c))))
+
+
+def _denblock_params(chns, in_ch, out_ch, interm_ch, blind):
+    c0, c1, c2 = chns
+    if blind:
+        in_ch = 3
+    return _Slots(
+        inc=_Slots(convblock=nn.ModuleDict({"0": _conv(in_ch, interm_ch), "3": _conv(interm_ch, c0)})),
+        downc0=_Slots(convblock=nn.ModuleDict({"0": _conv(c0, c1, 2)}), memconv=_mem(c1)),
+        downc1=_Slots(convblock=nn.ModuleDict({"0": _conv(c1, c2, 2)}), memconv=_mem(c2)),
+        upc2=_Slots(memconv=_mem(c2), convblock=nn.ModuleDict({"0": _conv(c2, 4 * c1)})),
+        upc1=_Slots(memconv=_mem(c1), convblock=nn.ModuleDict({"0": _conv(c1, 4 * c0)})),
+        outc=_Slots(convblock=nn.ModuleDict({"0": _conv(c0, c0), "3": _conv(c0, out_ch)})),
+    )
+
+
+@register_arch
+class BSVD(nn.Module):
+    """Bidirectional-buffer streaming video denoiser on MI355X.
+
+    Reference arguments (bsvd_arch.py:446-447) keep their meaning and defaults.  Engine-only keywords:
+      engine_mode : 'clip' (default; layer-major over the whole clip, 32 launches) or 'stream'
+                    (the reference's frame-major pipeline with 16-step latency).  Same function.
+      clamp       : optional (lo, hi) fused into the exit kernel (callers clamp to [0,1] anyway,
+                    validation_seq_infer.py:24).
+    """
+
+    def __init__(self, chns=[32, 64, 128], mid_ch=3, shift_input=False, in_ch=4, out_ch=3, norm='bn', act='relu',
+                 interm_ch=30, blind=False, pretrain_ckpt='./experiments/pretrained_ckpt/bsvd-64.pth',
+                 engine_mode='clip', clamp=None):
+        super().__init__()
+        if shift_input:
+            raise NotImplementedError("shift_input=True (CvBlock input stage) is not used by any BSVD config; "
+                                      "the reference itself is inconsistent there (SURVEY.md §8a-16)")
+        if norm != 'none':
+            raise NotImplementedError("norm=%r: the BSVD configs use norm='none' (options/test/bsvd_c64.yml:90); "
+                                      "normalisation layers are not implemented by the MI355X engine" % (norm,))
+        if engine_mode not in ("clip", "stream"):
+            raise ValueError("engine_mode must be 'clip' or 'stream'")
+        self.net = make_netspec(chns, mid_ch, in_ch, out_ch, act, interm_ch, blind)
+        self.engine_mode = engine_mode
+        self.clamp = clamp
+        self.temp1 = _denblock_params(self.net.chns, in_ch, mid_ch, interm_ch, blind)
+        self.temp2 = _denblock_params(self.net.chns, mid_ch, out_ch, interm_ch, False)
+        self.shift_num = self.net.shift_num
+        self.reset_params()
+        self._packed = None
+        self._packed_sig = None
+        self._exec = None
+        self._pipe = None
+        if pretrain_ckpt is not None:
+            self.load(pretrain_ckpt)
+
+    # ---- parameters ----------------------------------------------------------------------------
+    @staticmethod
+    def weight_init(m):
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, nonlinearity='relu')
+
+    def reset_params(self):
+        for m in self.modules():
+            self.weight_init(m)
+
+    def load(self, path):
+        ckpt = torch.load(path, map_location="cpu")
+        print("load from %s" % path)
+        state = ckpt['params'] if isinstance(ckpt, dict) and 'params' in ckpt else ckpt
+        self.load_state_dict(checkpoint.to_bsvd_state(state))
+
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version, str(p.device), p.dtype) for p in self.parameters())
+
+    def _executor(self, device):
+        from .engine import HipExecutor, PackedNet, require_hip
+        require_hip()
+        sig = (self._signature(), str(device))
+        if self._packed is None or self._packed_sig != sig:
+            self._packed = PackedNet(self.net, self.state_dict(), device)
+            self._packed_sig = sig
+            self._exec = HipExecutor(self._packed)
+        return self._exec
+
+    # ---- streaming protocol (bsvd_arch.py:459-461, 485-488) --------------------------------------
+    def reset(self):
+        if self._pipe is not None:
+            self._pipe.reset()
+
+    def _device(self):
+        if not torch.cuda.is_available():
+            raise RuntimeError("bsvd_amd.BSVD needs a HIP device (the reference hard-codes .cuda() too, "
+                               "bsvd_arch.py:94,104,520); no CPU fallback exists in the product path")
+        p = next(self.parameters())
+        return p.device if p.is_cuda else torch.device("cuda", torch.cuda.current_device())
+
+    def feedin_one_element(self, x):
+        """x: [1,C,H,W] tensor or None (flush).  Returns the frame fed ``shift_num`` steps earlier, or None."""
+        dev = self._device()
+        with torch.no_grad(), torch.cuda.device(dev):
+            ex = self._executor(dev)
+            if self._pipe is None:
+                self._pipe = StreamPipeline(self.net)
+            xin = None
+            out_dtype = torch.float32
+            if x is not None:
+                out_dtype = x.dtype if x.dtype in (torch.float16, torch.bfloat16) else torch.float32
+                xin = ex.to_nhwc(x.to(device=dev, dtype=torch.float32), self.net.temp1["inc0"].cin_pad)
+                self._last_dtype = out_dtype
+            y = self._pipe.feed(ex, xin)
+            if y is None:
+                return None
+            y = ex.to_nchw(y, self.net.out_ch, self.clamp)
+            return y.to(getattr(self, "_last_dtype", out_dtype))
+
+    def streaming_forward(self, input_seq):
+        """Pipeline-style inference over a clip (bsvd_arch.py:501-552): F data feeds, then flush feeds until
+        F + shift_num results exist; the first shift_num (None) are dropped; state is reset afterwards."""
+        if isinstance(input_seq, torch.Tensor):
+            input_seq = [input_seq[i:i + 1] for i in np.arange(input_seq.shape[0])]
+        assert type(input_seq) == list, "convert the input into a sequence"
+        outs = []
+        try:
+            for x in input_seq:
+                outs.append(self.feedin_one_element(x))
+            while len(outs) < self.shift_num + len(input_seq):
+                outs.append(self.feedin_one_element(None))
+            self.feedin_one_element(None)      # the reference's extra, discarded flush call (:541-542)
+        finally:
+            if self._pipe is not None:
+                self._pipe.clear()             # also after an exception: never leave stale buffers behind
+        return torch.cat(outs[self.shift_num:], dim=0)
+
+    # ---- clip forward (bsvd_arch.py:490-499) -----------------------------------------------------
+    def clip_forward(self, frames, halo_fn=None):
+        """frames: [T,C,H,W] -> [T,out_ch,H,W], layer-major over the whole clip."""
+        dev = self._device()
+        with torch.no_grad(), torch.cuda.device(dev):
+            ex = self._executor(dev)
+            out_dtype = frames.dtype if frames.dtype in (torch.float16, torch.bfloat16) else torch.float32
+            x = ex.to_nhwc(frames.to(device=dev, dtype=torch.float32), self.net.temp1["inc0"].cin_pad)
+            y = bsvd_clip(ex, self.net, x, halo_fn)
+            return ex.to_nchw(y, self.net.out_ch, self.clamp).to(out_dtype)
+
+    def forward(self, input, noise_map=None):
+        # N, F, C, H, W -> (N*F, C, H, W): like the reference, N>1 is one long clip
+        if noise_map is not None:
+            input = torch.cat([input, noise_map], dim=2)
+        N, F, C, H, W = input.shape
+        if C != self.net.net_in_ch:
+            raise ValueError("expected %d input channels (incl. noise map), got %d" % (self.net.net_in_ch, C))
+        if H % 4 or W % 4:
+            raise ValueError("H and W must be multiples of 4 (two 2x scales); DenoisingModel pads the input "
+                             "(denoising_model.py:133-159), got %dx%d" % (H, W))
+        frames = input.reshape(N * F, C, H, W)
+        if self.engine_mode == "stream":
+            out = self.streaming_forward(frames)
+        else:
+            out = self.clip_forward(frames)
+        return out.reshape(N, F, out.shape[1], H, W)
+
+    def count_shift(self):
+        return self.net.shift_num

@@ -1,0 +1,221 @@
+// bsvd_abi.hip -- C-ABI entry points of libbsvd_hip.so (see include/bsvd_hip.h): argument validation,
+// dispatch, and the small bandwidth-bound helper kernels (weight pre-pack, NCHW<->NHWC, halo pack).
+#include <stdarg.h>
+#include <stdio.h>
+#include "bsvd_internal.h"
+
+namespace bsvd {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight pre-pack: OIHW fp32 -> [Cin_pad/16][9][4][Cout_pad][4]
+__global__ void pack_weights_kernel(const float *__restrict__ w, const float *__restrict__ bias, int Cin, int Cout,
+                                    int Cin_pad, int Cout_pad, int ps, float *__restrict__ wp,
+                                    float *__restrict__ bp)
+{
+    const int64_t total = (int64_t)Cin_pad * 9 * Cout_pad;
+    const int Cq_pad = Cout_pad >> 2, Cq = Cout >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int j = t & 3; t >>= 2;
+        const int np = (int)(t % Cout_pad); t /= Cout_pad;
+        const int k4 = t & 3; t >>= 2;
+        const int tap = (int)(t % 9);
+        const int cb = (int)(t / 9);
+        const int c = cb * 16 + k4 * 4 + j;
+        int n = np;
+        bool ok = c < Cin;
+        if (ps) {
+            const int sub = np / Cq_pad, ch = np - sub * Cq_pad;
+            ok = ok && ch < Cq;
+            n = 4 * ch + sub;
+        } else {
+            ok = ok && np < Cout;
+        }
+        wp[i] = ok ? w[((int64_t)n * Cin + c) * 9 + tap] : 0.f;
+        if (bp && i < Cout_pad) {
+            int nb = (int)i;
+            bool okb;
+            if (ps) {
+                const int sub = nb / Cq_pad, ch = nb - sub * Cq_pad;
+                okb = ch < Cq;
+                nb = 4 * ch + sub;
+            } else {
+                okb = nb < Cout;
+            }
+            bp[i] = (okb && bias) ? bias[nb] : 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// clip entry / exit
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int HW, int Cpad,
+                                    int64_t total_pix)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total_pix;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = i / HW, pix = i - f * HW;
+        const float *s = src + f * (int64_t)C * HW + pix;
+        float *d = dst + i * Cpad;
+        for (int c = 0; c < Cpad; ++c) d[c] = c < C ? s[(int64_t)c * HW] : 0.f;
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int HW, int Cpad,
+                                    int64_t total_pix, int do_clamp, float lo, float hi)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total_pix;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = i / HW, pix = i - f * HW;
+        const float *s = src + i * Cpad;
+        float *d = dst + f * (int64_t)C * HW + pix;
+        for (int c = 0; c < C; ++c) {
+            float v = s[c];
+            if (do_clamp) v = fminf(fmaxf(v, lo), hi);
+            d[(int64_t)c * HW] = v;
+        }
+    }
+}
+
+__global__ void halo_pack_kernel(const float *__restrict__ frame, float *__restrict__ dst, int64_t total, int C, int c0,
+                                 int n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / n;
+        const int c = (int)(i - pix * n);
+        dst[i] = frame[pix * C + c0 + c];
+    }
+}
+
+static inline unsigned grid_for(int64_t n, int block)
+{
+    int64_t g = (n + block - 1) / block;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace bsvd
+
+using namespace bsvd;
+
+extern "C" {
+
+int bsvd_abi_version(void) { return BSVD_ABI_VERSION; }
+
+int bsvd_conv_args_size(void) { return (int)sizeof(BsvdConvArgs); }
+
+const char *bsvd_last_error(void) { return g_err; }
+
+int64_t bsvd_packed_weight_elems(int32_t Cin_pad, int32_t Cout_pad) { return (int64_t)Cin_pad * 9 * Cout_pad; }
+
+int bsvd_conv3x3(const BsvdConvArgs *a, void *stream)
+{
+    if (!a) { set_error("bsvd_conv3x3: args is NULL"); return -1; }
+    if (a->dtype != BSVD_F32) { set_error("bsvd_conv3x3: dtype %d not supported (BSVD_F32 only)", a->dtype); return -2; }
+    if (!a->x || !a->y || !a->w_packed) { set_error("bsvd_conv3x3: x, y and w_packed must be non-NULL"); return -3; }
+    if (a->frames <= 0 || a->H <= 0 || a->W <= 0) { set_error("bsvd_conv3x3: bad clip size %d x %d x %d", a->frames, a->H, a->W); return -4; }
+    if (a->Cin <= 0 || (a->Cin & 15) || a->Cout <= 0 || (a->Cout & 15)) {
+        set_error("bsvd_conv3x3: Cin=%d / Cout=%d must be positive multiples of 16 (pad channels)", a->Cin, a->Cout);
+        return -5;
+    }
+    if (a->stride != 1 && a->stride != 2) { set_error("bsvd_conv3x3: stride %d", a->stride); return -6; }
+    if (a->fold < 0 || 2 * a->fold > a->Cin) { set_error("bsvd_conv3x3: fold %d with Cin %d", a->fold, a->Cin); return -7; }
+    if (a->act < BSVD_ACT_NONE || a->act > BSVD_ACT_RELU6) { set_error("bsvd_conv3x3: act %d", a->act); return -8; }
+    if (a->epilogue < BSVD_EPI_PLAIN || a->epilogue > BSVD_EPI_RESID) { set_error("bsvd_conv3x3: epilogue %d", a->epilogue); return -9; }
+    if (a->epilogue == BSVD_EPI_PS_ADD && (a->Cout & 63)) { set_error("bsvd_conv3x3: PS_ADD needs Cout %% 64 == 0, got %d", a->Cout); return -10; }
+    if (a->epilogue == BSVD_EPI_RESID && (!a->extra || a->resid_ch < 0 || a->resid_ch > a->Cout)) {
+        set_error("bsvd_conv3x3: RESID needs extra and 0 <= resid_ch <= Cout"); return -11;
+    }
+    if (a->fold > 0) {
+        if (a->halo_prev && a->halo_prev_pstride <= 0) { set_error("bsvd_conv3x3: halo_prev_pstride"); return -12; }
+        if (a->halo_next && a->halo_next_pstride <= 0) { set_error("bsvd_conv3x3: halo_next_pstride"); return -12; }
+    }
+    ConvParams p;
+    p.x = (const float *)a->x;
+    p.halo_prev = a->fold > 0 ? (const float *)a->halo_prev : nullptr;
+    p.halo_next = a->fold > 0 ? (const float *)a->halo_next : nullptr;
+    p.w = (const float *)a->w_packed;
+    p.bias = (const float *)a->bias_packed;
+    p.extra = (const float *)a->extra;
+    p.y = (float *)a->y;
+    p.x_fs = a->x_frame_stride; p.extra_fs = a->extra_frame_stride; p.y_fs = a->y_frame_stride;
+    p.halo_prev_ps = a->halo_prev_pstride; p.halo_prev_co = a->halo_prev_coff;
+    p.halo_next_ps = a->halo_next_pstride; p.halo_next_co = a->halo_next_coff;
+    p.extra_ps = a->extra_pstride; p.extra_cs = a->extra_cstride; p.resid_ch = a->resid_ch;
+    p.fold = a->fold; p.frames = a->frames; p.H = a->H; p.W = a->W;
+    p.Ho = (a->H - 1) / a->stride + 1; p.Wo = (a->W - 1) / a->stride + 1;
+    p.Cin = a->Cin; p.Cout = a->Cout; p.act = a->act; p.epilogue = a->epilogue;
+    p.ntx = p.nty = p.nct = 0;
+    // 16-byte vector gather is legal when every 4-channel group has a single, aligned source
+    bool vec = (a->fold & 3) == 0 && (((uintptr_t)a->x) & 15) == 0 && (a->x_frame_stride & 3) == 0;
+    if (a->fold > 0 && a->halo_prev)
+        vec = vec && (a->halo_prev_pstride & 3) == 0 && (a->halo_prev_coff & 3) == 0 && (((uintptr_t)a->halo_prev) & 15) == 0;
+    if (a->fold > 0 && a->halo_next)
+        vec = vec && (a->halo_next_pstride & 3) == 0 && (a->halo_next_coff & 3) == 0 && (((uintptr_t)a->halo_next) & 15) == 0;
+    p.vec_ok = vec ? 1 : 0;
+    if ((((uintptr_t)a->w_packed) & 15) != 0) { set_error("bsvd_conv3x3: w_packed must be 16-byte aligned"); return -13; }
+    return launch_conv3x3_f32(p, a->stride, (hipStream_t)stream);
+}
+
+int bsvd_pack_weights(const float *w, const float *bias, int32_t Cin, int32_t Cout, int32_t Cin_pad, int32_t Cout_pad,
+                      int32_t pixel_shuffle, int32_t dtype, void *wp, void *bp, void *stream)
+{
+    if (dtype != BSVD_F32) { set_error("bsvd_pack_weights: dtype %d not supported", dtype); return -2; }
+    if (!w || !wp) { set_error("bsvd_pack_weights: NULL weight pointer"); return -3; }
+    if (Cin <= 0 || Cout <= 0 || Cin_pad < Cin || Cout_pad < Cout || (Cin_pad & 15) || (Cout_pad & 15)) {
+        set_error("bsvd_pack_weights: bad sizes Cin %d->%d Cout %d->%d", Cin, Cin_pad, Cout, Cout_pad); return -5;
+    }
+    if (pixel_shuffle && ((Cout & 3) || (Cout_pad & 63) || (Cout_pad >> 2) < (Cout >> 2))) {
+        set_error("bsvd_pack_weights: pixel_shuffle needs Cout %% 4 == 0 and Cout_pad %% 64 == 0"); return -10;
+    }
+    const int64_t total = bsvd_packed_weight_elems(Cin_pad, Cout_pad);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, w, bias, Cin,
+                       Cout, Cin_pad, Cout_pad, pixel_shuffle ? 1 : 0, (float *)wp, (float *)bp);
+    return (int)hipGetLastError();
+}
+
+int bsvd_nchw_to_nhwc(const float *src, void *dst, int32_t frames, int32_t C, int32_t H, int32_t W, int32_t C_pad,
+                      int32_t dtype, void *stream)
+{
+    if (dtype != BSVD_F32) { set_error("bsvd_nchw_to_nhwc: dtype %d not supported", dtype); return -2; }
+    if (!src || !dst || frames <= 0 || C <= 0 || H <= 0 || W <= 0 || C_pad < C) { set_error("bsvd_nchw_to_nhwc: bad arguments"); return -3; }
+    const int64_t total = (int64_t)frames * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (float *)dst, C, H * W, C_pad, total);
+    return (int)hipGetLastError();
+}
+
+int bsvd_nhwc_to_nchw(const void *src, float *dst, int32_t frames, int32_t C, int32_t H, int32_t W, int32_t C_pad,
+                      int32_t dtype, int32_t do_clamp, float lo, float hi, void *stream)
+{
+    if (dtype != BSVD_F32) { set_error("bsvd_nhwc_to_nchw: dtype %d not supported", dtype); return -2; }
+    if (!src || !dst || frames <= 0 || C <= 0 || H <= 0 || W <= 0 || C_pad < C) { set_error("bsvd_nhwc_to_nchw: bad arguments"); return -3; }
+    const int64_t total = (int64_t)frames * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)src, dst, C, H * W, C_pad, total, do_clamp, lo, hi);
+    return (int)hipGetLastError();
+}
+
+int bsvd_halo_pack(const void *frame, void *dst, int32_t HW, int32_t C, int32_t c0, int32_t n, int32_t dtype,
+                   void *stream)
+{
+    if (dtype != BSVD_F32) { set_error("bsvd_halo_pack: dtype %d not supported", dtype); return -2; }
+    if (!frame || !dst || HW <= 0 || C <= 0 || c0 < 0 || n <= 0 || c0 + n > C) { set_error("bsvd_halo_pack: bad arguments"); return -3; }
+    const int64_t total = (int64_t)HW * n;
+    hipLaunchKernelGGL(halo_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)frame, (float *)dst, total, C, c0, n);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,32 @@
+// Internal declarations shared by the translation units of libbsvd_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bsvd_hip.h"
+
+namespace bsvd {
+
+// Kernel-side view of BsvdConvArgs (validated, typed, with derived tiling numbers).
+struct ConvParams {
+    const float *x;
+    const float *halo_prev;
+    const float *halo_next;
+    const float *w;
+    const float *bias;
+    const float *extra;
+    float *y;
+    int64_t x_fs, extra_fs, y_fs;
+    int32_t halo_prev_ps, halo_prev_co, halo_next_ps, halo_next_co;
+    int32_t extra_ps, extra_cs, resid_ch;
+    int32_t fold, frames, H, W, Ho, Wo, Cin, Cout;
+    int32_t act, epilogue;
+    int32_t ntx, nty, nct;   // tiles in x, y and output-channel tiles
+    int32_t vec_ok;          // 1: every 4-channel group of the gather comes from one source, 16-B aligned
+};
+
+void set_error(const char *fmt, ...);
+
+// conv3x3_f32_mfma.hip
+int launch_conv3x3_f32(const ConvParams &p, int stride, hipStream_t stream);
+
+}  // namespace bsvd

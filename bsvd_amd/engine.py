@@ -1,0 +1,134 @@
+"""HIP executor: runs netspec layers on the MI355X through the C ABI (libbsvd_hip.so).
+
+PyTorch is used only as plumbing here -- device memory (caching allocator), the current HIP stream and
+tensor hand-over at the nn.Module boundary.  All arithmetic happens in the hand-written kernels.
+There is deliberately no CPU path: without a HIP device / the built library this module raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .netspec import EPI_PLAIN, EPI_PS_ADD, EPI_RESID  # noqa: F401
+from .schedule import Halo  # noqa: F401
+
+
+def require_hip():
+    if not torch.cuda.is_available():
+        raise RuntimeError("bsvd_amd needs a HIP device (MI355X); torch.cuda.is_available() is False. "
+                           "There is no CPU fallback -- the CPU restatement lives in oracle/ for tests only.")
+    return _lib.load()
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class PackedNet:
+    """Device-resident pre-packed weights of every layer (one-time transform of the state_dict,
+    cf. BSVD.load, bsvd_arch.py:462-474): {spec.key: (w_packed, bias_packed)}."""
+
+    def __init__(self, net, state, device):
+        lib = require_hip()
+        self.device = device
+        self.tensors = {}
+        with torch.cuda.device(device):
+            for sp in net.layers:
+                w = state[sp.key + ".weight"].detach().to(device=device, dtype=torch.float32).contiguous()
+                b = state.get(sp.key + ".bias")
+                if b is not None:
+                    b = b.detach().to(device=device, dtype=torch.float32).contiguous()
+                if tuple(w.shape) != (sp.cout, sp.cin, 3, 3):
+                    raise ValueError("%s.weight has shape %s, expected %s" % (sp.key, tuple(w.shape), (sp.cout, sp.cin, 3, 3)))
+                n = lib.bsvd_packed_weight_elems(sp.cin_pad, sp.cout_pad)
+                wp = torch.empty(n, dtype=torch.float32, device=device)
+                bp = torch.empty(sp.cout_pad, dtype=torch.float32, device=device)
+                rc = lib.bsvd_pack_weights(w.data_ptr(), b.data_ptr() if b is not None else None, sp.cin, sp.cout,
+                                           sp.cin_pad, sp.cout_pad, 1 if sp.epilogue == EPI_PS_ADD else 0, _lib.BSVD_F32,
+                                           wp.data_ptr(), bp.data_ptr(), _stream_ptr())
+                _lib.check(rc, "bsvd_pack_weights(%s)" % sp.key)
+                self.tensors[sp.key] = (wp, bp)
+            # w/b temporaries are consumed by kernels queued on the current stream; the caching allocator
+            # keeps stream order, so letting them go out of scope here is safe.
+
+
+class HipExecutor:
+    """conv()/to_nhwc()/to_nchw() on device tensors; every call enqueues exactly one kernel on the
+    current HIP stream."""
+
+    def __init__(self, packed):
+        self.lib = require_hip()
+        self.packed = packed
+        self.device = packed.device
+        self.launches = 0
+
+    # -- layout at the clip boundary ------------------------------------------------------------
+    def to_nhwc(self, x_nchw, c_pad):
+        """[T,C,H,W] fp32 contiguous device tensor -> [T,H,W,c_pad]"""
+        T, C, H, W = x_nchw.shape
+        x_nchw = x_nchw.contiguous()
+        y = torch.empty((T, H, W, c_pad), dtype=torch.float32, device=x_nchw.device)
+        rc = self.lib.bsvd_nchw_to_nhwc(x_nchw.data_ptr(), y.data_ptr(), T, C, H, W, c_pad, _lib.BSVD_F32, _stream_ptr())
+        _lib.check(rc, "bsvd_nchw_to_nhwc")
+        self.launches += 1
+        return y
+
+    def to_nchw(self, x_nhwc, c, clamp=None):
+        T, H, W, c_pad = x_nhwc.shape
+        y = torch.empty((T, c, H, W), dtype=torch.float32, device=x_nhwc.device)
+        lo, hi = (0.0, 0.0) if clamp is None else clamp
+        rc = self.lib.bsvd_nhwc_to_nchw(x_nhwc.data_ptr(), y.data_ptr(), T, c, H, W, c_pad, _lib.BSVD_F32,
+                                        0 if clamp is None else 1, lo, hi, _stream_ptr())
+        _lib.check(rc, "bsvd_nhwc_to_nchw")
+        self.launches += 1
+        return y
+
+    def halo_pack(self, frame, c0, n):
+        """compact [H,W,n] copy of channels [c0,c0+n) of one NHWC frame [H,W,C] (message to a neighbour shard)"""
+        H, W, C = frame.shape[-3:]
+        out = torch.empty((H, W, n), dtype=torch.float32, device=frame.device)
+        rc = self.lib.bsvd_halo_pack(frame.data_ptr(), out.data_ptr(), H * W, C, c0, n, _lib.BSVD_F32, _stream_ptr())
+        _lib.check(rc, "bsvd_halo_pack")
+        self.launches += 1
+        return out
+
+    # -- the fused layer -------------------------------------------------------------------------
+    def conv(self, sp, x, halo_prev=None, halo_next=None, extra=None, extra_pstride=0, extra_cstride=1):
+        T, H, W, cin_pad = x.shape
+        if cin_pad != sp.cin_pad:
+            raise ValueError("%s: input has %d channels, layer expects %d" % (sp.key, cin_pad, sp.cin_pad))
+        if not x.is_contiguous():
+            raise ValueError("%s: input must be contiguous NHWC" % sp.key)
+        Ho, Wo = (H - 1) // sp.stride + 1, (W - 1) // sp.stride + 1
+        if sp.epilogue == EPI_PS_ADD:
+            y = torch.empty((T, 2 * Ho, 2 * Wo, sp.cout_pad // 4), dtype=torch.float32, device=x.device)
+        else:
+            y = torch.empty((T, Ho, Wo, sp.cout_pad), dtype=torch.float32, device=x.device)
+        wp, bp = self.packed.tensors[sp.key]
+        a = _lib.BsvdConvArgs()
+        a.x = x.data_ptr()
+        a.x_frame_stride = H * W * cin_pad
+        if sp.tsm:
+            a.fold = sp.fold
+            if halo_prev is not None:
+                a.halo_prev, a.halo_prev_pstride, a.halo_prev_coff = halo_prev.t.data_ptr(), halo_prev.pstride, halo_prev.coff
+            if halo_next is not None:
+                a.halo_next, a.halo_next_pstride, a.halo_next_coff = halo_next.t.data_ptr(), halo_next.pstride, halo_next.coff
+        a.w_packed, a.bias_packed = wp.data_ptr(), bp.data_ptr()
+        if extra is not None:
+            a.extra = extra.data_ptr()
+            a.extra_frame_stride = extra[0].numel()
+            a.extra_pstride, a.extra_cstride = extra_pstride, extra_cstride
+        elif sp.epilogue == EPI_RESID:
+            raise ValueError("%s: the residual layer needs its base tensor" % sp.key)
+        a.resid_ch = min(3, sp.cout) if sp.epilogue == EPI_RESID else 0
+        a.y = y.data_ptr()
+        a.y_frame_stride = y[0].numel()
+        a.frames, a.H, a.W = T, H, W
+        a.Cin, a.Cout = sp.cin_pad, sp.cout_pad
+        a.stride = sp.stride
+        a.act, a.epilogue, a.dtype = _lib.ACT[sp.act], sp.epilogue, _lib.BSVD_F32
+        rc = self.lib.bsvd_conv3x3(ctypes.byref(a), _stream_ptr())
+        _lib.check(rc, "bsvd_conv3x3(%s)" % sp.key)
+        self.launches += 1
+        return y

@@ -1,0 +1,167 @@
+"""Host-side schedules of the BSVD forward over an abstract layer executor.
+
+Two schedules over the SAME fused layers (netspec.ConvSpec -> one ``bsvd_conv3x3`` launch each):
+
+* ``denblock_clip`` / ``bsvd_clip``: layer-major over a whole clip [T,H,W,C]; the temporal shift reads
+  frames t-1 / t+1 of the same tensor inside the kernel, zeros (or a neighbour shard's halo) past the
+  ends.  32 launches per clip.  Equivalent to the reference's streaming loop.
+* ``StreamPipeline``: frame-major, the reference's own pipeline
+  (/root/reference/Experimental_root/archs/bsvd_arch.py:53-114 BiBufferConv, :308-322 MemSkip,
+  :374-396 DenBlock.forward, :485-488 feedin_one_element) with its None-in/None-out protocol and
+  16-step latency; the "two streaming frame buffers" of every temporal-fusion conv are device tensors
+  handed to the kernel as halo_prev / x / halo_next -- no concatenated copy is ever made.
+
+The executor (``ex``) only has to provide ``conv(spec, x, halo_prev=None, halo_next=None, extra=None,
+extra_pstride=0, extra_cstride=1)`` on NHWC tensors; the product uses engine.HipExecutor (HIP kernels).
+"""
+from collections import deque, namedtuple
+
+# A temporal neighbour slice: element (pixel p, channel j of the slice) lives at t.flatten()[p*pstride + coff + j]
+Halo = namedtuple("Halo", ["t", "pstride", "coff"])
+
+
+# ------------------------------------------------------------------------------------------ clip mode
+def denblock_clip(ex, S, x, halo_fn=None):
+    """One DenBlock over a clip.  x: [T,H,W,cin_pad] NHWC.  halo_fn(spec, x) -> (Halo|None, Halo|None)
+    supplies the neighbour shards' boundary slices when the clip is a frame-window shard."""
+
+    def tsm(name, v):
+        hp = hn = None
+        if halo_fn is not None:
+            hp, hn = halo_fn(S[name], v)
+        return ex.conv(S[name], v, halo_prev=hp, halo_next=hn)
+
+    a = ex.conv(S["inc0"], x)
+    x0 = ex.conv(S["inc3"], a)
+    del a
+    d = ex.conv(S["down0"], x0)
+    x1 = tsm("d0c2", tsm("d0c1", d))
+    d = ex.conv(S["down1"], x1)
+    x2 = tsm("d1c2", tsm("d1c1", d))
+    del d
+    u = tsm("u2c2", tsm("u2c1", x2))
+    del x2
+    v = ex.conv(S["up2"], u, extra=x1, extra_pstride=x1.shape[-1])        # PixelShuffle + skip3
+    del u, x1
+    v = tsm("u1c2", tsm("u1c1", v))
+    w = ex.conv(S["up1"], v, extra=x0, extra_pstride=x0.shape[-1])        # PixelShuffle + skip2
+    del v, x0
+    o = ex.conv(S["out0"], w)
+    del w
+    return ex.conv(S["out3"], o, extra=x, extra_pstride=x.shape[-1])      # residual vs. the block input
+
+
+def bsvd_clip(ex, net, x, halo_fn=None):
+    y = denblock_clip(ex, net.temp1, x, halo_fn)
+    return denblock_clip(ex, net.temp2, y, halo_fn)
+
+
+# ---------------------------------------------------------------------------------------- stream mode
+class _TsmStage:
+    """The two frame buffers around one temporal-fusion conv (BiBufferConv, bsvd_arch.py:53-114).
+
+    feed(frame t+1) returns the layer output for frame t.  ``mid`` = pending frame, ``past`` = the frame
+    before it (its channels [fold:2fold] are what ShiftConv reads; None = zeros at stream start).
+    Like the reference, ``past`` survives a flush and is only cleared by reset()."""
+
+    def __init__(self, spec):
+        self.spec = spec
+        self.mid = None
+        self.past = None
+        self.past_valid = False
+
+    def reset(self):
+        self.mid = None
+        self.past = None
+        self.past_valid = False
+
+    def feed(self, ex, nxt):
+        if self.mid is None:
+            self.mid = nxt
+            if nxt is not None and not self.past_valid:
+                self.past, self.past_valid = None, True     # zeros
+            return None
+        cur, sp = self.mid, self.spec
+        cpad = cur.shape[-1]
+        hp = None if self.past is None else Halo(self.past, cpad, sp.fold)
+        hn = None if nxt is None else Halo(nxt, cpad, 0)
+        y = ex.conv(sp, cur, halo_prev=hp, halo_next=hn)
+        self.past, self.mid = cur, nxt
+        return y
+
+
+class _SkipFifo:
+    """MemSkip (bsvd_arch.py:308-322)."""
+
+    def __init__(self):
+        self.q = deque()
+
+    def push(self, v):
+        if v is not None:
+            self.q.append(v)
+
+    def pop_if(self, partner):
+        return self.q.popleft() if partner is not None else None
+
+    def __len__(self):
+        return len(self.q)
+
+
+class _DenBlockStream:
+    def __init__(self, S):
+        self.S = S
+        self.stage = {n: _TsmStage(S[n]) for n in S if S[n].tsm}
+        self.skip_in, self.skip_x0, self.skip_x1 = _SkipFifo(), _SkipFifo(), _SkipFifo()
+
+    def reset(self):       # DenBlock.reset only resets the BiBufferConvs (bsvd_arch.py:352-356)
+        for st in self.stage.values():
+            st.reset()
+
+    def clear(self):
+        self.reset()
+        for f in (self.skip_in, self.skip_x0, self.skip_x1):
+            f.q.clear()
+
+    def _pair(self, ex, a, b, v):
+        return self.stage[b].feed(ex, self.stage[a].feed(ex, v))
+
+    def feed(self, ex, x):
+        S = self.S
+        self.skip_in.push(x)
+        x0 = None if x is None else ex.conv(S["inc3"], ex.conv(S["inc0"], x))
+        self.skip_x0.push(x0)
+        d = None if x0 is None else ex.conv(S["down0"], x0)
+        x1 = self._pair(ex, "d0c1", "d0c2", d)
+        self.skip_x1.push(x1)
+        d = None if x1 is None else ex.conv(S["down1"], x1)
+        x2 = self._pair(ex, "d1c1", "d1c2", d)
+        u = self._pair(ex, "u2c1", "u2c2", x2)
+        sk = self.skip_x1.pop_if(u)
+        v = None if u is None else ex.conv(S["up2"], u, extra=sk, extra_pstride=sk.shape[-1])
+        v = self._pair(ex, "u1c1", "u1c2", v)
+        sk = self.skip_x0.pop_if(v)
+        w = None if v is None else ex.conv(S["up1"], v, extra=sk, extra_pstride=sk.shape[-1])
+        base = self.skip_in.pop_if(w)
+        if w is None:
+            return None
+        return ex.conv(S["out3"], ex.conv(S["out0"], w), extra=base, extra_pstride=base.shape[-1])
+
+
+class StreamPipeline:
+    """feedin_one_element on device buffers: x is a [1,H,W,cin_pad] NHWC tensor or None (flush)."""
+
+    def __init__(self, net):
+        self.t1 = _DenBlockStream(net.temp1)
+        self.t2 = _DenBlockStream(net.temp2)
+        self.shift_num = net.shift_num
+
+    def reset(self):
+        self.t1.reset()
+        self.t2.reset()
+
+    def clear(self):
+        self.t1.clear()
+        self.t2.clear()
+
+    def feed(self, ex, x):
+        return self.t2.feed(ex, self.t1.feed(ex, x))

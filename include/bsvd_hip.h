@@ -1,0 +1,129 @@
+/*
+ * bsvd_hip.h -- C ABI of libbsvd_hip.so: the MI355X (gfx950) kernels behind the BSVD hot path.
+ *
+ * The reference has no FFI on this path: everything below BSVD.forward is torch ops
+ * (/root/reference/Experimental_root/archs/bsvd_arch.py).  This header is the boundary the
+ * MI355X engine puts in their place; each entry point names the reference op(s) it replaces.
+ * The Python host (bsvd_amd/) binds it with ctypes; any other host binds it the same way
+ * (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no torch / C++ types; no exceptions cross the ABI.
+ *   - The library allocates nothing and keeps no global state besides a thread-local error string.
+ *     Every buffer (activations, packed weights, halos) is owned and sized by the caller.
+ *   - All work is enqueued asynchronously on the caller's HIP stream (pass it as void*, i.e. a
+ *     hipStream_t; NULL = the default stream).  Calls on distinct streams may run concurrently.
+ *   - Return value: 0 ok; <0 invalid argument (text via bsvd_last_error()); >0 a hipError_t.
+ *   - Activations are NHWC ("channels last"): element (f, y, x, c) of a clip lives at
+ *         base + f*frame_stride + (y*W + x)*C + c        (strides in ELEMENTS)
+ *     with C already padded by the caller to a multiple of 16 (padded channels hold zeros).
+ *   - dtype: BSVD_F32 is the exact-fp32 mode (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain).
+ */
+#ifndef BSVD_HIP_H
+#define BSVD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSVD_ABI_VERSION 1
+
+enum { BSVD_F32 = 0, BSVD_F16 = 1 };                       /* dtype                                  */
+enum { BSVD_ACT_NONE = 0, BSVD_ACT_RELU = 1, BSVD_ACT_RELU6 = 2 }; /* get_act_function, bsvd_arch.py:185-192 */
+enum {
+    BSVD_EPI_PLAIN = 0,   /* y = act(conv + bias)                                                     */
+    BSVD_EPI_PS_ADD = 1,  /* nn.PixelShuffle(2) (+ skip add): UpBlock :265-266 + DenBlock.none_add :402 */
+    BSVD_EPI_RESID = 2    /* y[:resid_ch] = extra[:resid_ch] - y[:resid_ch]: DenBlock.none_minus :408-414 */
+};
+
+/*
+ * One fused layer over a whole clip (or a single frame in streaming mode):
+ *
+ *     y[f] = epilogue( act( conv3x3( gather(x[f-1], x[f], x[f+1], fold), w, stride, pad 1 ) + bias ) )
+ *
+ * Replaces, per call: nn.Conv2d 3x3 (bsvd_arch.py:31-38, 208-213, 238, 265, 295-298), the
+ * torch.cat temporal-shift gather of ShiftConv.forward (:42-50), the zero tensors BiBufferConv makes
+ * at stream start/end (:94, :104), nn.ReLU6/ReLU (:185-192), nn.PixelShuffle(2) (:266), the skip add
+ * (:402-406) and the residual (:408-414).
+ *
+ * Temporal-shift gather (fold > 0): input channel c of frame f is read from
+ *     frame f+1  if c <  fold            (for f == frames-1: from halo_next, zeros if NULL)
+ *     frame f-1  if fold <= c < 2*fold   (for f == 0:        from halo_prev, zeros if NULL)
+ *     frame f    otherwise.
+ * Halo element (pixel p, channel c) is read at
+ *     halo_prev[p*halo_prev_pstride + halo_prev_coff + (c - fold)],
+ *     halo_next[p*halo_next_pstride + halo_next_coff + c].
+ * (compact [H][W][fold] slice: pstride = fold, coff = 0; a full NHWC frame: pstride = Cin,
+ *  coff = fold resp. 0.)  This is what a neighbouring frame-window shard sends over RCCL, and in
+ *  streaming mode it is BiBufferConv's left_fold_2fold / input_right.
+ */
+typedef struct BsvdConvArgs {
+    const void *x;              /* [frames][H][W][Cin]                                              */
+    int64_t x_frame_stride;     /* elements between consecutive frames of x                          */
+    const void *halo_prev;      /* nullable */
+    const void *halo_next;      /* nullable */
+    int32_t halo_prev_pstride, halo_prev_coff;
+    int32_t halo_next_pstride, halo_next_coff;
+    int32_t fold;               /* 0 = plain conv (no temporal shift)                                */
+    const void *w_packed;       /* from bsvd_pack_weights()                                          */
+    const void *bias_packed;    /* [Cout] from bsvd_pack_weights(); nullable                         */
+    const void *extra;          /* PS_ADD: skip tensor laid out like y (nullable); RESID: base tensor */
+    int64_t extra_frame_stride;
+    int32_t extra_pstride;      /* elements between pixels of extra                                  */
+    int32_t extra_cstride;      /* elements between channels of extra                                */
+    int32_t resid_ch;           /* RESID: number of leading channels replaced (3 in the reference)   */
+    void *y;                    /* PLAIN/RESID: [frames][Ho][Wo][Cout]; PS_ADD: [frames][2Ho][2Wo][Cout/4] */
+    int64_t y_frame_stride;
+    int32_t frames, H, W;       /* input spatial size; Ho = (H-1)/stride + 1                          */
+    int32_t Cin, Cout;          /* padded channel counts: Cin % 16 == 0, Cout % 16 == 0 (PS_ADD: Cout % 64 == 0) */
+    int32_t stride;             /* 1 or 2                                                            */
+    int32_t act, epilogue, dtype;
+} BsvdConvArgs;
+
+int bsvd_abi_version(void);
+int bsvd_conv_args_size(void);   /* sizeof(BsvdConvArgs) as compiled into the library (binding sanity check) */
+const char *bsvd_last_error(void);
+
+/* The fused layer above.  Exact fp32 on MFMA (BSVD_F32). */
+int bsvd_conv3x3(const BsvdConvArgs *args, void *stream);
+
+/*
+ * Re-orders one nn.Conv2d weight [Cout][Cin][3][3] (+ bias [Cout]) into the layout bsvd_conv3x3
+ * streams through LDS: w_packed[Cin_pad/16][9][4][Cout_pad][4] (the last index runs over 4
+ * consecutive input channels), zero-filled padding.  pixel_shuffle != 0 additionally permutes the
+ * output channels so that the four PixelShuffle sub-pixels become four contiguous channel groups:
+ *   packed column sub*(Cout_pad/4) + c   <-   original output channel 4*c + sub.
+ * Sizes: w_packed needs bsvd_packed_weight_elems(Cin_pad, Cout_pad) elements, bias_packed Cout_pad.
+ * (One-time transform of the tensors BSVD.load() produces, bsvd_arch.py:462-474.)
+ */
+int64_t bsvd_packed_weight_elems(int32_t Cin_pad, int32_t Cout_pad);
+int bsvd_pack_weights(const float *w_oihw, const float *bias, int32_t Cin, int32_t Cout,
+                      int32_t Cin_pad, int32_t Cout_pad, int32_t pixel_shuffle, int32_t dtype,
+                      void *w_packed, void *bias_packed, void *stream);
+
+/*
+ * Clip entry/exit: the reference feeds NCHW tensors (BSVD.forward reshape, bsvd_arch.py:494-499,
+ * and torch.cat(out_seq_clip) :552); callers then clamp to [0,1] (validation_seq_infer.py:24).
+ *   nchw_to_nhwc: src [frames][C][H][W] fp32  ->  dst [frames][H][W][C_pad] (zero padded channels)
+ *   nhwc_to_nchw: src [frames][H][W][C_pad]   ->  dst [frames][C][H][W] fp32, optional clamp to [lo,hi]
+ */
+int bsvd_nchw_to_nhwc(const float *src, void *dst, int32_t frames, int32_t C, int32_t H, int32_t W,
+                      int32_t C_pad, int32_t dtype, void *stream);
+int bsvd_nhwc_to_nchw(const void *src, float *dst, int32_t frames, int32_t C, int32_t H, int32_t W,
+                      int32_t C_pad, int32_t dtype, int32_t do_clamp, float lo, float hi, void *stream);
+
+/*
+ * Frame-window sharding: gathers the channel slice [c0, c0+n) of one NHWC frame into
+ * a compact [H*W][n] buffer -- the message a rank sends to its temporal neighbour
+ * (first frame, c0 = 0 -> the left neighbour's halo_next; last frame, c0 = fold -> the right
+ * neighbour's halo_prev).
+ */
+int bsvd_halo_pack(const void *frame, void *dst, int32_t HW, int32_t C, int32_t c0, int32_t n,
+                   int32_t dtype, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSVD_HIP_H */

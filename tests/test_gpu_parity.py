@@ -1,0 +1,242 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference goldens.
+Run on the MI355X box:  python -m pytest tests -m gpu
+
+Tolerance: north_star asks <= 1e-3 max-abs vs the fp32 CPU forward; the exact-fp32 MFMA path is held to
+1e-4 here (fp32 rounding/association differences only; outputs are O(10))."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, bsvd_keys, state_for, maxabs
+from oracle_exec import OracleExecutor
+from seeded import seeded_state, state_digest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda", 0)
+
+
+def _gpu_exec(net, st):
+    from bsvd_amd.engine import HipExecutor, PackedNet
+    return HipExecutor(PackedNet(net, {k: torch.as_tensor(v) for k, v in st.items()}, _dev()))
+
+
+def _one_layer_net(cin, cout, stride, tsm, act, epi):
+    """A NetSpec-like object holding a single layer, so PackedNet/HipExecutor can be used per layer."""
+    from bsvd_amd.netspec import ConvSpec
+
+    class One:
+        pass
+
+    sp = ConvSpec("l", "l", cin, cout, stride, tsm, act, epi)
+    o = One()
+    o.layers = [sp]
+    return o, sp
+
+
+LAYER_CASES = [
+    # cin, cout, stride, tsm, act, epi, T, H, W
+    (4, 64, 1, False, "relu6", 0, 2, 20, 36),       # first layer: Cin padded 4 -> 16
+    (64, 64, 1, False, "relu6", 0, 1, 33, 50),      # 256px x 64ch tile config, ragged edges
+    (128, 128, 1, True, "relu6", 0, 3, 10, 19),     # temporal shift, fold 16, odd sizes
+    (256, 256, 1, True, "relu", 0, 4, 9, 17),       # fold 32, K = 2304, 2 cout tiles
+    (64, 128, 2, False, "relu6", 0, 2, 20, 36),     # stride 2
+    (128, 256, 2, False, "relu6", 0, 1, 27, 43),    # stride 2, odd input size
+    (32, 64, 2, False, "relu", 0, 2, 16, 24),       # stride 2, narrow Cout (masked columns)
+    (256, 512, 1, False, "none", 1, 2, 9, 13),      # PixelShuffle + skip (Cq = 128)
+    (128, 256, 1, False, "none", 1, 1, 12, 20),     # PixelShuffle + skip (Cq = 64)
+    (64, 64, 1, False, "none", 2, 2, 12, 20),       # residual on first 3 channels, 64-ch base
+    (64, 3, 1, False, "none", 2, 2, 12, 20),        # last layer: Cout 3 -> pad 16
+    (24, 40, 1, True, "relu6", 0, 3, 8, 12),        # fold = 3 (not a multiple of 4): scalar gather path
+    (30, 64, 1, False, "relu", 0, 1, 8, 12),        # blind net's interm_ch = 30
+]
+
+
+@pytest.mark.parametrize("cin,cout,stride,tsm,act,epi,T,H,W", LAYER_CASES)
+def test_layer_vs_oracle(cin, cout, stride, tsm, act, epi, T, H, W):
+    from bsvd_amd.netspec import pad16
+    from bsvd_amd.schedule import Halo
+    rs = np.random.RandomState(cin * 1000 + cout + stride)
+    st = seeded_state([("l.weight", (cout, cin, 3, 3)), ("l.bias", (cout,))], 7)
+    net, sp = _one_layer_net(cin, cout, stride, tsm, act, epi)
+    gex, oex = _gpu_exec(net, st), OracleExecutor(st, double=True)
+    x = torch.zeros((T, H, W, pad16(cin)))
+    x[..., :cin] = torch.from_numpy(rs.standard_normal((T, H, W, cin)).astype(np.float32))
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    extra, eps = None, 0
+    if epi == 1:
+        cqp = sp.cout_pad // 4
+        extra = torch.zeros((T, 2 * Ho, 2 * Wo, cqp))
+        extra[..., :cout // 4] = torch.from_numpy(rs.standard_normal((T, 2 * Ho, 2 * Wo, cout // 4)).astype(np.float32))
+        eps = cqp
+    elif epi == 2:
+        extra = torch.from_numpy(rs.standard_normal((T, Ho, Wo, 16)).astype(np.float32))
+        eps = 16
+    halos = [(None, None)]
+    if tsm:
+        fold = sp.fold
+        hp = torch.from_numpy(rs.standard_normal((H, W, fold)).astype(np.float32))
+        hn = torch.from_numpy(rs.standard_normal((H, W, fold)).astype(np.float32))
+        full = torch.from_numpy(rs.standard_normal((1, H, W, pad16(cin))).astype(np.float32))
+        halos += [(Halo(hp, fold, 0), Halo(hn, fold, 0)), (Halo(full, pad16(cin), fold), Halo(full, pad16(cin), 0))]
+    for hp, hn in halos:
+        want = oex.conv(sp, x, hp, hn, extra, eps, 1)
+        d = lambda h: None if h is None else Halo(h.t.to(_dev()), h.pstride, h.coff)
+        got = gex.conv(sp, x.to(_dev()), d(hp), d(hn), None if extra is None else extra.to(_dev()), eps, 1)
+        torch.cuda.synchronize()
+        assert got.shape == want.shape
+        assert maxabs(got.cpu().numpy(), want.numpy()) < TOL
+
+
+def test_layout_roundtrip_and_clamp():
+    net, sp = _one_layer_net(16, 16, 1, False, "none", 0)
+    gex = _gpu_exec(net, seeded_state([("l.weight", (16, 16, 3, 3)), ("l.bias", (16,))], 1))
+    x = torch.randn(3, 5, 14, 22)
+    n = gex.to_nhwc(x.to(_dev()), 16)
+    assert torch.equal(n[..., :5].cpu(), x.permute(0, 2, 3, 1)) and float(n[..., 5:].abs().max()) == 0
+    assert torch.equal(gex.to_nchw(n, 5).cpu(), x)
+    assert torch.equal(gex.to_nchw(n, 3, (0.0, 1.0)).cpu(), x[:, :3].clamp(0, 1))
+    assert torch.equal(gex.halo_pack(n[1], 2, 3).cpu(), x[1, 2:5].permute(1, 2, 0))
+
+
+def _module(chns, mid_ch, interm_ch, act, st, blind=False, mode="clip"):
+    import bsvd_amd
+    m = bsvd_amd.BSVD(chns=chns, mid_ch=mid_ch, in_ch=4, out_ch=3, norm="none", act=act, interm_ch=interm_ch,
+                      blind=blind, pretrain_ckpt=None, engine_mode=mode)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
+    return m.to(_dev())
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 7])
+def test_golden_small_net(T):
+    g = load_golden("g4_bsvd_small_T%d" % T)
+    st = state_for(g, bsvd_keys([32, 64, 128], 32, 4, 3, 32))
+    x = torch.from_numpy(g["x"]).to(_dev())
+    yc = _module([32, 64, 128], 32, 32, "relu6", st, mode="clip")(x)
+    ys = _module([32, 64, 128], 32, 32, "relu6", st, mode="stream")(x)
+    assert maxabs(yc.cpu().numpy(), g["out"]) < TOL
+    assert maxabs(ys.cpu().numpy(), g["out"]) < TOL
+    assert torch.equal(yc, ys), "clip and stream schedules run the same kernels on the same operands"
+
+
+def test_golden_default_ctor_odd_channels():
+    g = load_golden("g4b_bsvd_defaults")
+    st = state_for(g, bsvd_keys([32, 64, 128], 3, 4, 3, 30))
+    x = torch.from_numpy(g["x"]).to(_dev())
+    m = _module([32, 64, 128], 3, 30, "relu", st)
+    y = m(x[:, :, :3], noise_map=x[:, :, 3:4])
+    assert maxabs(y.cpu().numpy(), g["out"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_golden_c64(tag):
+    g = load_golden("g5_bsvd_c64_" + tag)
+    st = state_for(g, bsvd_keys([64, 128, 256], 64, 4, 3, 64))
+    m = _module([64, 128, 256], 64, 64, "relu6", st)
+    y = m(torch.from_numpy(g["x"]).to(_dev()))
+    assert maxabs(y.cpu().numpy(), g["out"]) < TOL
+    if tag == "c":
+        m.engine_mode = "stream"
+        assert maxabs(m(torch.from_numpy(g["x"]).to(_dev())).cpu().numpy(), g["out"]) < TOL
+
+
+def test_golden_blind_from_tsn_checkpoint(tmp_path):
+    from bsvd_amd import checkpoint
+    g = load_golden("g6_blind_c64")
+    tsn = seeded_state([(k, tuple(int(v) for v in s.split(","))) for k, s in zip(g["tsn_keys"], g["tsn_shapes"])],
+                       int(g["seed"]))
+    assert state_digest(tsn) == str(g["digest"])
+    p = tmp_path / "tsn.pth"
+    torch.save({"params": {"module." + k: torch.from_numpy(v) for k, v in tsn.items()}}, p)
+    import bsvd_amd
+    m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, norm="none", act="relu", interm_ch=30, blind=True,
+                      pretrain_ckpt=str(p)).to(_dev())
+    y = m(torch.from_numpy(g["x"]).to(_dev()))
+    assert maxabs(y.cpu().numpy(), g["out"]) < TOL
+
+
+def test_feedin_one_element_protocol():
+    """None-in/None-out protocol and 16-step latency of the streaming API (bsvd_arch.py:485-552)."""
+    g = load_golden("g4_bsvd_small_T3")
+    st = state_for(g, bsvd_keys([32, 64, 128], 32, 4, 3, 32))
+    m = _module([32, 64, 128], 32, 32, "relu6", st, mode="stream")
+    x = torch.from_numpy(g["x"][0]).to(_dev())
+    sched, outs = [], []
+    for v in [x[i:i + 1] for i in range(3)] + [None] * 17:
+        y = m.feedin_one_element(v)
+        sched.append([v is None, y is None])
+        if y is not None:
+            outs.append(y)
+    assert sched == [list(map(bool, s)) for s in g["schedule"]]
+    assert maxabs(torch.cat(outs).cpu().numpy(), g["out"][0]) < TOL
+    m.reset()
+
+
+def test_sharded_equals_unsharded_bitwise():
+    """Two frame-window shards with per-layer halos == the unsharded clip, bit for bit."""
+    from bsvd_amd.netspec import make_netspec
+    from bsvd_amd.schedule import Halo, bsvd_clip
+    g = load_golden("g5_bsvd_c64_a")
+    st = state_for(g, bsvd_keys([64, 128, 256], 64, 4, 3, 64))
+    net = make_netspec([64, 128, 256], 64, 4, 3, "relu6", 64)
+    x = torch.from_numpy(g["x"][0]).to(_dev())
+    ex = _gpu_exec(net, st)
+    whole = ex.to_nchw(bsvd_clip(ex, net, ex.to_nhwc(x, 16)), 3)
+    boxes, results = {}, [None, None]
+    barrier = threading.Barrier(2)
+
+    def rank(r, frames):
+        torch.cuda.set_device(0)
+        e = _gpu_exec(net, st)
+
+        def halo_fn(sp, v):
+            fold = sp.fold
+            boxes[(r, sp.key)] = (e.halo_pack(v[0], 0, fold), e.halo_pack(v[-1], fold, fold))
+            torch.cuda.synchronize()
+            barrier.wait()
+            other = boxes[(1 - r, sp.key)]
+            barrier.wait()
+            return (None, Halo(other[0], fold, 0)) if r == 0 else (Halo(other[1], fold, 0), None)
+
+        results[r] = e.to_nchw(bsvd_clip(e, net, e.to_nhwc(frames, 16), halo_fn), 3)
+        torch.cuda.synchronize()
+
+    th = [threading.Thread(target=rank, args=(0, x[:2])), threading.Thread(target=rank, args=(1, x[2:]))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert torch.equal(torch.cat(results), whole)
+    assert maxabs(whole.cpu().numpy(), g["out"][0]) < TOL
+
+
+def test_full_resolution_two_frames_vs_oracle():
+    """BASELINE config 1 geometry (540x960, bsvd_c64), 2 frames: HIP vs the torch CPU oracle."""
+    from oracle import bsvd_oracle as O
+    st = seeded_state(bsvd_keys([64, 128, 256], 64, 4, 3, 64), 11)
+    from seeded import seeded_clip
+    x = torch.from_numpy(seeded_clip((1, 2, 4, 540, 960), 12, kind="sigma30"))
+    m = _module([64, 128, 256], 64, 64, "relu6", st)
+    y = m(x.to(_dev())).cpu()
+    want = O.bsvd_clip(x, O.to_torch_state(st))
+    assert maxabs(y.numpy(), want.numpy()) < 1e-3
+    m.engine_mode = "stream"
+    assert torch.equal(m(x.to(_dev())).cpu(), y)
+
+
+def test_rejects_bad_arguments():
+    from bsvd_amd import _lib
+    import ctypes
+    lib = _lib.load()
+    a = _lib.BsvdConvArgs()
+    assert lib.bsvd_conv3x3(ctypes.byref(a), None) < 0
+    assert b"non-NULL" in lib.bsvd_last_error()
+    import bsvd_amd
+    m = bsvd_amd.BSVD(norm="none", pretrain_ckpt=None).to(_dev())
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 2, 4, 18, 26, device=_dev()))     # not a multiple of 4 (reference fails at the skip add)

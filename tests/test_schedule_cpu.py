@@ -1,0 +1,153 @@
+"""Host logic of the product (netspec layer list, channel padding, clip and stream schedules, checkpoint
+key map) driven on CPU through the oracle-backed executor and checked against the reference goldens.
+The HIP kernels are not involved here (see test_gpu_*.py for those)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, bsvd_keys, state_for, maxabs
+from oracle_exec import OracleExecutor
+from seeded import seeded_state, state_digest
+from bsvd_amd import checkpoint
+from bsvd_amd.netspec import make_netspec, pad16
+from bsvd_amd.schedule import StreamPipeline, bsvd_clip, Halo
+
+TOL = 1e-4
+
+
+def run_clip(net, st, x5):
+    ex = OracleExecutor(st)
+    x = torch.from_numpy(x5).reshape(-1, *x5.shape[2:])
+    xin = ex.to_nhwc(x, net.temp1["inc0"].cin_pad)
+    y = ex.to_nchw(bsvd_clip(ex, net, xin), net.out_ch)
+    return y.numpy().reshape(x5.shape[0], x5.shape[1], net.out_ch, *x5.shape[3:]), ex
+
+
+def run_stream(net, st, x5, schedule=None):
+    ex = OracleExecutor(st)
+    pipe = StreamPipeline(net)
+    x = torch.from_numpy(x5).reshape(-1, *x5.shape[2:])
+    T = x.shape[0]
+    outs = []
+
+    def feed(v):
+        xin = None if v is None else ex.to_nhwc(v, net.temp1["inc0"].cin_pad)
+        y = pipe.feed(ex, xin)
+        if schedule is not None:
+            schedule.append([v is None, y is None])
+        return None if y is None else ex.to_nchw(y, net.out_ch)
+
+    for t in range(T):
+        outs.append(feed(x[t:t + 1]))
+    while len(outs) < T + pipe.shift_num:
+        outs.append(feed(None))
+    feed(None)
+    y = torch.cat(outs[pipe.shift_num:]).numpy()
+    return y.reshape(x5.shape[0], x5.shape[1], net.out_ch, *x5.shape[3:]), pipe
+
+
+def test_macs_and_shift_num_c64():
+    net = make_netspec([64, 128, 256], 64, 4, 3, "relu6", 64)
+    assert net.macs_per_frame(540, 960) == 613_619_712_000
+    assert net.shift_num == 16
+    assert len(net.layers) == 32 and sum(l.tsm for l in net.layers) == 16
+    blind = make_netspec([64, 128, 256], 64, 4, 3, "relu", 30, blind=True)
+    assert abs(blind.macs_per_frame(540, 960) / 1e9 - 582.4) < 0.1
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 7])
+def test_small_net_clip_and_stream(T):
+    g = load_golden("g4_bsvd_small_T%d" % T)
+    st = state_for(g, bsvd_keys([32, 64, 128], 32, 4, 3, 32))
+    net = make_netspec([32, 64, 128], 32, 4, 3, "relu6", 32)
+    y, ex = run_clip(net, st, g["x"])
+    assert ex.launches == 32
+    assert maxabs(y, g["out"]) < TOL
+    sched = []
+    y, pipe = run_stream(net, st, g["x"], sched)
+    assert sched == [list(map(bool, s)) for s in g["schedule"]]
+    assert maxabs(y, g["out"]) < TOL
+    # a completed flush leaves the skip FIFOs empty
+    for blk in (pipe.t1, pipe.t2):
+        assert len(blk.skip_in) == len(blk.skip_x0) == len(blk.skip_x1) == 0
+
+
+def test_default_ctor_odd_channels():
+    """mid_ch=3, interm_ch=30, fold=4: exercises channel padding (3->16, 30->32) in every role."""
+    g = load_golden("g4b_bsvd_defaults")
+    st = state_for(g, bsvd_keys([32, 64, 128], 3, 4, 3, 30))
+    net = make_netspec()        # reference constructor defaults
+    assert (net.temp1["out3"].cout_pad, net.temp2["inc0"].cin_pad, net.temp1["inc0"].cout_pad) == (16, 16, 32)
+    y, _ = run_clip(net, st, g["x"])
+    assert maxabs(y, g["out"]) < TOL
+    y, _ = run_stream(net, st, g["x"])
+    assert maxabs(y, g["out"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["a", "c"])
+def test_c64_clip(tag):
+    g = load_golden("g5_bsvd_c64_" + tag)
+    st = state_for(g, bsvd_keys([64, 128, 256], 64, 4, 3, 64))
+    net = make_netspec([64, 128, 256], 64, 4, 3, "relu6", 64)
+    y, _ = run_clip(net, st, g["x"])
+    assert maxabs(y, g["out"]) < TOL
+
+
+def test_blind_wnet_semantics_and_tsn_checkpoint_keys():
+    g = load_golden("g6_blind_c64")
+    tsn = seeded_state([(k, tuple(int(v) for v in s.split(","))) for k, s in zip(g["tsn_keys"], g["tsn_shapes"])],
+                       int(g["seed"]))
+    assert state_digest(tsn) == str(g["digest"])
+    assert checkpoint.is_tsn_schema(tsn)
+    st = checkpoint.to_bsvd_state(tsn)
+    net = make_netspec([64, 128, 256], 64, 4, 3, "relu", 30, blind=True)
+    assert net.net_in_ch == 3 and net.temp2["inc0"].cin == 64
+    y, _ = run_clip(net, st, g["x"])
+    assert maxabs(y, g["out"]) < TOL
+
+
+def test_checkpoint_keymap_matches_reference_load():
+    g = load_golden("g7_ckpt_keymap")
+    for src, dst in zip(g["tsn_keys"], g["bsvd_keys"]):
+        assert checkpoint.tsn_key_to_bsvd("module." + str(src)) == str(dst)
+        assert checkpoint.tsn_key_to_bsvd(str(src)) == str(dst)
+    assert checkpoint.tsn_key_to_bsvd("something.else") is None
+    plain = {"module.temp1.inc.convblock.0.weight": 1}
+    assert list(checkpoint.to_bsvd_state(plain)) == ["temp1.inc.convblock.0.weight"]
+
+
+def test_sharded_clip_with_halos_equals_whole_clip():
+    """Frame-window sharding: two shards exchanging per-layer 1-frame halos == one clip."""
+    g = load_golden("g4_bsvd_small_T7")
+    st = state_for(g, bsvd_keys([32, 64, 128], 32, 4, 3, 32))
+    net = make_netspec([32, 64, 128], 32, 4, 3, "relu6", 32)
+    x = torch.from_numpy(g["x"][0])
+    cut = 3
+    # run both shards in lock-step, layer by layer, using python generators as "ranks"
+    import threading
+    boxes = {}
+    barrier = threading.Barrier(2)
+    results = [None, None]
+
+    def rank(r, frames):
+        ex = OracleExecutor(st)
+
+        def halo_fn(sp, v):
+            fold = sp.fold
+            mine = {"first": ex.halo_pack(v[0], 0, fold), "last": ex.halo_pack(v[-1], fold, fold)}
+            boxes[(r, sp.key)] = mine
+            barrier.wait()
+            other = boxes[(1 - r, sp.key)]
+            barrier.wait()
+            if r == 0:
+                return None, Halo(other["first"], fold, 0)
+            return Halo(other["last"], fold, 0), None
+
+        xin = ex.to_nhwc(frames, net.temp1["inc0"].cin_pad)
+        results[r] = ex.to_nchw(bsvd_clip(ex, net, xin, halo_fn), net.out_ch)
+
+    th = [threading.Thread(target=rank, args=(0, x[:cut])), threading.Thread(target=rank, args=(1, x[cut:]))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    y = torch.cat(results).numpy()
+    assert maxabs(y, g["out"][0]) < TOL
