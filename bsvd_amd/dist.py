@@ -1,0 +1,64 @@
+"""Frame-window sharding of one clip over the GPUs of a node (new component; the reference has no
+multi-GPU inference -- /root/reference/Experimental_root/models/validation_seq_infer.py:24 notes it
+"cannot work on multiple gpu").  SURVEY.md §8e.
+
+Rank r owns a contiguous window of frames and runs the clip schedule on it.  The only cross-rank
+dependency is the temporal shift: each of the 16 temporal-fusion convs needs ``fold`` channels of the
+frame before its window (from rank r-1's last frame) and ``fold`` channels of the frame after it (from
+rank r+1's first frame) of THAT layer's input.  ``HaloExchanger`` is the ``halo_fn`` of
+schedule.bsvd_clip: it packs the two boundary slices with ``bsvd_halo_pack`` and swaps them with the
+temporal neighbours using point-to-point send/recv (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests).  Neighbour-only traffic: no all-reduce, one xGMI link per direction.
+The outermost ranks see zeros, exactly the stream start/end of the reference (bsvd_arch.py:94,104).
+"""
+import torch
+import torch.distributed as dist
+
+from .schedule import Halo
+
+
+def shard_range(num_frames, world, rank):
+    """Contiguous, balanced frame window [start, end) of ``rank``."""
+    base, rem = divmod(num_frames, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+class HaloExchanger:
+    def __init__(self, ex, rank=None, world=None, group=None):
+        self.ex = ex
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.bytes_sent = 0
+        self.exchanges = 0
+
+    def __call__(self, spec, v):
+        """v: [T,H,W,C] input of temporal-fusion layer ``spec`` on this rank -> (Halo|None, Halo|None)."""
+        fold = spec.fold
+        has_left, has_right = self.rank > 0, self.rank + 1 < self.world
+        if fold == 0 or not (has_left or has_right):
+            return None, None
+        H, W = v.shape[1:3]
+        ops, recv_prev, recv_next = [], None, None
+        if has_right:
+            send_last = self.ex.halo_pack(v[-1], fold, fold)          # my last frame's [fold:2fold] -> right's halo_prev
+            recv_next = torch.empty((H, W, fold), dtype=v.dtype, device=v.device)
+            ops += [dist.P2POp(dist.isend, send_last, self._peer(self.rank + 1), self.group),
+                    dist.P2POp(dist.irecv, recv_next, self._peer(self.rank + 1), self.group)]
+            self.bytes_sent += send_last.numel() * send_last.element_size()
+        if has_left:
+            send_first = self.ex.halo_pack(v[0], 0, fold)             # my first frame's [0:fold] -> left's halo_next
+            recv_prev = torch.empty((H, W, fold), dtype=v.dtype, device=v.device)
+            ops += [dist.P2POp(dist.isend, send_first, self._peer(self.rank - 1), self.group),
+                    dist.P2POp(dist.irecv, recv_prev, self._peer(self.rank - 1), self.group)]
+            self.bytes_sent += send_first.numel() * send_first.element_size()
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()          # NCCL/RCCL: orders the current stream after the transfer, no host sync
+        self.exchanges += 1
+        hp = None if recv_prev is None else Halo(recv_prev, fold, 0)
+        hn = None if recv_next is None else Halo(recv_next, fold, 0)
+        return hp, hn
+
+    def _peer(self, group_rank):
+        return group_rank if self.group is None else dist.get_global_rank(self.group, group_rank)
