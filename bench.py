@@ -90,12 +90,31 @@ class LaunchTimer:
         return agg
 
 
+def usable_cores():
+    """Host cores this process may really use: min(affinity mask, cgroup CPU quota).  The GPU box exposes 256
+    logical CPUs but a 16-CPU cgroup quota; oversubscribing it makes oneDNN ~10x slower (tools/cpu_probe.py)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(model):
     """Reference CPU path stand-in: oracle.stream_forward (per-frame pipeline, F.conv2d fp32 + torch.cat) on
     the host cores.  Bounded sample, adaptively sized to ~10-30 s of CPU work."""
     from oracle import bsvd_oracle as O
     P = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     with torch.no_grad():
         lq, nm = synth_clip(1, 7, "cpu")

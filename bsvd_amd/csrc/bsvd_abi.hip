@@ -2,6 +2,7 @@
 // dispatch, and the small bandwidth-bound helper kernels (weight pre-pack, NCHW<->NHWC, halo pack).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "bsvd_internal.h"
 
 namespace bsvd {
@@ -164,6 +165,10 @@ int bsvd_conv3x3(const BsvdConvArgs *a, void *stream)
     if (a->fold > 0 && a->halo_next)
         vec = vec && (a->halo_next_pstride & 3) == 0 && (a->halo_next_coff & 3) == 0 && (((uintptr_t)a->halo_next) & 15) == 0;
     p.vec_ok = vec ? 1 : 0;
+    p.ablate = 0;
+#ifdef BSVD_ABLATE
+    if (const char *e = getenv("BSVD_ABLATE")) p.ablate = atoi(e);
+#endif
     if ((((uintptr_t)a->w_packed) & 15) != 0) { set_error("bsvd_conv3x3: w_packed must be 16-byte aligned"); return -13; }
     return launch_conv3x3_f32(p, a->stride, (hipStream_t)stream);
 }

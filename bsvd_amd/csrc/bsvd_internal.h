@@ -22,6 +22,7 @@ struct ConvParams {
     int32_t act, epilogue;
     int32_t ntx, nty, nct;   // tiles in x, y and output-channel tiles
     int32_t vec_ok;          // 1: every 4-channel group of the gather comes from one source, 16-B aligned
+    int32_t ablate;          // only read by -DBSVD_ABLATE timing builds (tools/), always 0 in the product
 };
 
 void set_error(const char *fmt, ...);

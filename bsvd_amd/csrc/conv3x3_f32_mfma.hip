@@ -49,7 +49,7 @@ struct ConvCfg {
     static constexpr int W_ITEMS = 4 * BN;             // float4 items per weight slab
     static constexpr int W_PER_THREAD = W_ITEMS / 256;
     static_assert(W_ITEMS % 256 == 0, "");
-    static constexpr int LDS_BYTES = (2 * PATCH_FLOATS + 2 * W_FLOATS) * 4;
+    static constexpr int LDS_BYTES = 2 * PATCH_FLOATS * 4;
 };
 
 struct SrcSel {            // per-frame sources of the temporal-shift gather (wave uniform)
@@ -124,11 +124,10 @@ __device__ __forceinline__ float apply_act(float v, int act)
 }
 
 template <class C>
-__global__ __launch_bounds__(256) void conv3x3_f32_kernel(const ConvParams p)
+__global__ __launch_bounds__(256, 3) void conv3x3_f32_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *const patch_buf = smem;                              // 2 x PATCH_FLOATS
-    float *const w_buf = smem + 2 * C::PATCH_FLOATS;            // 2 x W_FLOATS
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -158,11 +157,16 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const ConvParams p)
     else                  { s.next = p.halo_next; s.next_ps = p.halo_next_ps; s.next_co = p.halo_next_co; }
 
     const int ncb = p.Cin >> 4;
-    const int64_t slab_stride = (int64_t)16 * p.Cout;           // floats per (chunk, tap) slab
+    const int64_t slab_stride = (int64_t)16 * p.Cout;           // floats per (chunk, tap) weight slab
 
-    // ---- per-lane LDS read offsets (floats)
+    // ---- per-lane offsets.  A fragments come from the LDS patch; B fragments (weights) are read straight
+    //      from global/L2 into registers in the packed [k4][Cout][4] layout: lanes = consecutive output
+    //      channels -> one coalesced 512-B run per half-wave, no LDS round trip and no per-tap barrier.
     const int a_lane = (((4 * wm + (li >> 4)) * C::STRIDE) * C::PW + (li & 15) * C::STRIDE) * C::PS + lh * 4;
-    const int b_lane = (lh * C::BN + wn * 64 + li) * 4;
+    const int nb0 = n0 + wn * 64 + li;                           // this lane's output channel for nt = 0 (+32 for nt = 1)
+    const bool nok0 = nb0 < p.Cout, nok1 = nb0 + 32 < p.Cout;
+    const float *wl = p.w + ((int64_t)lh * p.Cout + nb0) * 4;
+    const int64_t g_off = (int64_t)8 * p.Cout;                  // floats between k4 = 2g+lh and 2(g+1)+lh
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -172,52 +176,61 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const ConvParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    // ---- prologue: chunk 0 patch + slab (0,0)
-    for (int e = tid; e < C::NQ; e += 256) store_patch_quad<C>(patch_buf, e, load_patch_quad<C>(p, s, 0, e, iy0, ix0));
+    auto load_b = [&](int step, f32x4 (&b)[2][2]) {
+        const float *sl = wl + (int64_t)step * slab_stride;
 #pragma unroll
-    for (int i = 0; i < C::W_PER_THREAD; ++i) {
-        const int e = tid + i * 256;
-        *reinterpret_cast<f32x4 *>(w_buf + e * 4) = load_w_item<C>(p.w, e, n0, p.Cout);
-    }
+        for (int g = 0; g < 2; ++g) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            b[0][g] = nok0 ? *reinterpret_cast<const f32x4 *>(sl + g * g_off) : z;
+            b[1][g] = nok1 ? *reinterpret_cast<const f32x4 *>(sl + g * g_off + 128) : z;
+        }
+    };
+    auto load_a = [&](const float *pc, int tap, f32x4 (&a)[2][2]) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const float *ap = pc + a_lane + (ky * C::PW + kx) * C::PS;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                a[mt][g] = *reinterpret_cast<const f32x4 *>(ap + (2 * mt * C::STRIDE * C::PW) * C::PS + g * 8);
+    };
+
+    // ---- prologue: chunk 0 patch -> LDS, weights of step 0 -> registers
+    f32x4 bcur[2][2], bnxt[2][2];
+    load_b(0, bcur);
+    for (int e = tid; e < C::NQ; e += 256) store_patch_quad<C>(patch_buf, e, load_patch_quad<C>(p, s, 0, e, iy0, ix0));
     __syncthreads();
 
-    int step = 0;
     for (int cb = 0; cb < ncb; ++cb) {
         const float *pcur = patch_buf + (cb & 1) * C::PATCH_FLOATS;
         float *pnext = patch_buf + ((cb + 1) & 1) * C::PATCH_FLOATS;
         const bool more_chunks = cb + 1 < ncb;
-        for (int tap = 0; tap < 9; ++tap, ++step) {
-            const float *wcur = w_buf + (step & 1) * C::W_FLOATS;
-            float *wnext = w_buf + ((step + 1) & 1) * C::W_FLOATS;
-            const bool more_steps = more_chunks || tap < 8;
-
-            // (1) issue the global loads of step+1 (weights) and 1/9 of the next chunk's patch
-            f32x4 wreg[C::W_PER_THREAD];
-            if (more_steps) {
-                const float *slab = p.w + (int64_t)(step + 1) * slab_stride;
-#pragma unroll
-                for (int i = 0; i < C::W_PER_THREAD; ++i) wreg[i] = load_w_item<C>(slab, tid + i * 256, n0, p.Cout);
-            }
+        f32x4 acur[2][2], anxt[2][2];
+        load_a(pcur, 0, acur);
+#ifdef BSVD_ABLATE
+        load_a(pcur, 0, anxt);
+        load_b(0, bnxt);
+#endif
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            // (1) global loads for the next step: weights -> registers, 1/9 of the next chunk's patch
+#ifdef BSVD_ABLATE   // timing-only ablation build (results invalid): p.ablate bit0 = no weight loads, bit1 = no patch prefetch, bit2 = no A reads
+            if ((tap < 8 || more_chunks) && !(p.ablate & 1)) load_b(cb * 9 + tap + 1, bnxt);
+            const int ep = tap * C::Q_PER_STEP + tid;
+            const bool do_p = more_chunks && tid < C::Q_PER_STEP && ep < C::NQ && !(p.ablate & 2);
+#else
+            if (tap < 8 || more_chunks) load_b(cb * 9 + tap + 1, bnxt);
             const int ep = tap * C::Q_PER_STEP + tid;
             const bool do_p = more_chunks && tid < C::Q_PER_STEP && ep < C::NQ;
+#endif
             f32x4 preg = {0.f, 0.f, 0.f, 0.f};
             if (do_p) preg = load_patch_quad<C>(p, s, cb + 1, ep, iy0, ix0);
-
-            // (2) fragments from LDS, 32 MFMAs
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const float *ap = pcur + a_lane + (ky * C::PW + kx) * C::PS;
-            const float *bp = wcur + b_lane;
-            f32x4 a[2][2], b[2][2];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-                    a[mt][g] = *reinterpret_cast<const f32x4 *>(ap + (2 * mt * C::STRIDE * C::PW) * C::PS + g * 8);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-                    b[nt][g] = *reinterpret_cast<const f32x4 *>(bp + (2 * g * C::BN + nt * 32) * 4);
+            // (2) next tap's A fragments (same patch) while this tap's 32 MFMAs run
+#ifdef BSVD_ABLATE
+            if (tap < 8 && !(p.ablate & 4)) load_a(pcur, tap + 1, anxt);
+#else
+            if (tap < 8) load_a(pcur, tap + 1, anxt);
+#endif
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -226,18 +239,19 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const ConvParams p)
                     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][g][j], b[nt][g][j],
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[mt][g][j], bcur[nt][g][j],
                                                                                acc[mt][nt], 0, 0, 0);
-
-            // (3) land the prefetched data in the other buffers; one barrier per step
-            if (more_steps) {
-#pragma unroll
-                for (int i = 0; i < C::W_PER_THREAD; ++i)
-                    *reinterpret_cast<f32x4 *>(wnext + (tid + i * 256) * 4) = wreg[i];
-            }
+            // (3) land the prefetched patch slice in the other buffer; rotate registers
             if (do_p) store_patch_quad<C>(pnext, ep, preg);
-            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    acur[u][g] = anxt[u][g];
+                    bcur[u][g] = bnxt[u][g];
+                }
         }
+        __syncthreads();   // one barrier per 16-channel chunk (9 taps, 288 MFMAs per wave)
     }
 
     // ---- epilogue.  C/D layout of 32x32 MFMA: col (n) = lane&31, row (m) = (r&3) + 8*(r>>2) + 4*(lane>>5);
