@@ -7,21 +7,25 @@
 //
 // Workgroup = 4 waves (256 threads), output tile = (TH x 16) pixels x BN channels.  Each wave owns a
 // 64-pixel (4 rows x 16 cols) x 64-channel sub-tile = 2x2 MFMA tiles = 64 accumulator VGPRs.
-// K is walked as (channel chunk of 16) x (9 taps):
-//   * per channel chunk the (TH*s+2) x (16*s+2) x 16ch input patch incl. the 1-pixel halo is staged
-//     ONCE in LDS and reused by all 9 taps and all BN output channels; the temporal-shift gather is
-//     folded into this staging load as a per-channel-group source select (no torch.cat copy);
-//   * per (chunk, tap) a 16 x BN weight slab is staged in LDS.
-// Both are double buffered: the global loads for step s+1 are issued before the 32 MFMAs of step s
-// and written to the other LDS buffer after them -> one barrier per step (2048 MFMA cycles).
+// K is walked as (channel chunk of 16) x (9 taps), 32 MFMAs per wave per (chunk, tap) step:
+//   * A operand: per channel chunk the input patch incl. the 1-pixel halo is staged ONCE in LDS and reused
+//     by all 9 taps and all BN output channels; the temporal-shift gather is folded into this staging
+//     load as a source select (no torch.cat copy).  The next chunk's patch is prefetched in row slices
+//     during the taps of the current chunk (double-buffered LDS, one barrier per chunk = 288 MFMAs).
+//   * B operand: weights go straight from global/L2 to VGPRs in the pre-packed [k4][Cout][4] layout
+//     (lanes = consecutive output channels -> coalesced 512-B runs); no LDS round trip, no per-tap barrier.
 //
-// LDS images
-//   patch : [pixel][16 ch + 4 pad] floats (80-B pixel stride keeps ds_read_b128 16-B aligned and spreads
-//           consecutive pixels over the 64 banks)
-//   weight: [k4 = 4][BN][4] floats, i.e. 4 consecutive input channels per 16-B item
-// K-order trick: lane l of a 32x32x2 MFMA supplies k = l>>5.  A ds_read_b128 gives a lane 4 consecutive
-// channels; MFMA j (0..3) then uses k = 8g + 4(l>>5) + j on both operands -- any K permutation is legal
-// as long as A and B agree, so all LDS reads are 16-byte wide.
+// FAST path (fold % 16 == 0, 16-B aligned operands; every bsvd_c64 layer): each 16-channel chunk has a
+// single temporal source, so all global reads are branch-free raw buffer loads (out-of-range lanes read 0
+// = zero padding / masking for free) and the weight fragments run TWO steps ahead in a 3-deep register
+// ring, the patch slices one step ahead in a second ring.  Measured on MI355X the memory latency seen by a
+// wave under this load is several thousand cycles (PMC: 23 % of wave time parked in s_waitcnt with a 1-step
+// prefetch), which is what the deeper rings hide.  GENERIC path: any fold / alignment, per-element select.
+//
+// LDS patch image: [pixel][16 ch + 4 pad] floats (80-B pixel stride keeps ds_read_b128 16-B aligned and
+// spreads consecutive pixels over the banks).  K-order trick: lane l of a 32x32x2 MFMA supplies k = l>>5;
+// a 16-byte read gives a lane 4 consecutive channels and MFMA j (0..3) uses k = 8g + 4(l>>5) + j on both
+// operands -- any K permutation is legal as long as A and B agree, so every operand read is 16 bytes wide.
 //
 // Reference ops replaced: see include/bsvd_hip.h (bsvd_conv3x3).
 #include "bsvd_internal.h"
@@ -30,6 +34,7 @@ namespace bsvd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int TH_, int WM_, int WN_, int STRIDE_>
 struct ConvCfg {
@@ -42,14 +47,21 @@ struct ConvCfg {
     static constexpr int PS = 20;                      // floats per patch pixel
     static constexpr int NP = PH * PW;                 // patch pixels
     static constexpr int NQ = NP * 4;                  // float4 items per patch chunk
-    static constexpr int Q_PER_STEP = (NQ + 8) / 9;    // spread the next patch's loads over 9 taps
-    static_assert(Q_PER_STEP <= 256, "one prefetch item per thread per step");
     static constexpr int PATCH_FLOATS = NP * PS;
-    static constexpr int W_FLOATS = 16 * BN;
-    static constexpr int W_ITEMS = 4 * BN;             // float4 items per weight slab
-    static constexpr int W_PER_THREAD = W_ITEMS / 256;
-    static_assert(W_ITEMS % 256 == 0, "");
     static constexpr int LDS_BYTES = 2 * PATCH_FLOATS * 4;
+    // generic path: next patch spread over the 9 taps
+    static constexpr int Q_PER_STEP = (NQ + 8) / 9;
+    static constexpr int QG = (Q_PER_STEP + 255) / 256;          // items per thread per tap
+    // fast path: next patch in row slices; a thread owns one (column, channel-quad) of R rows per pass
+    static constexpr int ROW_ITEMS = PW * 4;                     // float4 items per patch row
+    static_assert(ROW_ITEMS <= 256, "a patch row must fit one pass of the workgroup");
+    static constexpr int R = 256 / ROW_ITEMS;                    // rows covered by one pass
+    static constexpr int P = (PH + 8 * R - 1) / (8 * R);         // passes per slice so that <= 8 slices
+    static constexpr int ROWS_PER_SLICE = R * P;
+    static constexpr int NSLICE = (PH + ROWS_PER_SLICE - 1) / ROWS_PER_SLICE;
+    static_assert(NSLICE <= 8, "slices are loaded at taps 0..7 and stored at taps 1..8");
+    // workgroups per CU the LDS footprint admits (160 KiB) -> register budget for __launch_bounds__
+    static constexpr int OCC = LDS_BYTES > 80 * 1024 ? 1 : (LDS_BYTES > 53 * 1024 ? 2 : 3);
 };
 
 struct SrcSel {            // per-frame sources of the temporal-shift gather (wave uniform)
@@ -106,16 +118,6 @@ __device__ __forceinline__ void store_patch_quad(float *patch, int e, f32x4 v)
     *reinterpret_cast<f32x4 *>(patch + pix * C::PS + q * 4) = v;
 }
 
-template <class C>
-__device__ __forceinline__ f32x4 load_w_item(const float *slab, int e, int n0, int Cout)
-{
-    const int k4 = e / C::BN, nn = e % C::BN;
-    const int n = n0 + nn;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (n < Cout) v = *reinterpret_cast<const f32x4 *>(slab + ((int64_t)k4 * Cout + n) * 4);
-    return v;
-}
-
 __device__ __forceinline__ float apply_act(float v, int act)
 {
     if (act >= BSVD_ACT_RELU) v = fmaxf(v, 0.f);
@@ -123,8 +125,29 @@ __device__ __forceinline__ float apply_act(float v, int act)
     return v;
 }
 
-template <class C>
-__global__ __launch_bounds__(256, 3) void conv3x3_f32_kernel(const ConvParams p)
+// ------------------------------------------------------------------------------------------------------
+// fast-path helpers: raw buffer loads (lanes with an out-of-range offset read 0)
+#define BSVD_OOB 0x7fffffffu
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *ptr, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ptr), 0, bytes, 0x00020000);
+}
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+struct ChunkSrc {          // wave-uniform description of one 16-channel chunk's source
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned ps4;          // pixel stride in bytes
+    unsigned soff;         // byte offset of the chunk's first channel inside a pixel
+};
+
+// ------------------------------------------------------------------------------------------------------
+template <class C, bool FAST>
+__global__ __launch_bounds__(256, C::OCC) void conv3x3_f32_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *const patch_buf = smem;                              // 2 x PATCH_FLOATS
@@ -157,16 +180,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_f32_kernel(const ConvParams p)
     else                  { s.next = p.halo_next; s.next_ps = p.halo_next_ps; s.next_co = p.halo_next_co; }
 
     const int ncb = p.Cin >> 4;
-    const int64_t slab_stride = (int64_t)16 * p.Cout;           // floats per (chunk, tap) weight slab
 
-    // ---- per-lane offsets.  A fragments come from the LDS patch; B fragments (weights) are read straight
-    //      from global/L2 into registers in the packed [k4][Cout][4] layout: lanes = consecutive output
-    //      channels -> one coalesced 512-B run per half-wave, no LDS round trip and no per-tap barrier.
+    // A fragments: per-lane offset into the LDS patch (floats)
     const int a_lane = (((4 * wm + (li >> 4)) * C::STRIDE) * C::PW + (li & 15) * C::STRIDE) * C::PS + lh * 4;
     const int nb0 = n0 + wn * 64 + li;                           // this lane's output channel for nt = 0 (+32 for nt = 1)
-    const bool nok0 = nb0 < p.Cout, nok1 = nb0 + 32 < p.Cout;
-    const float *wl = p.w + ((int64_t)lh * p.Cout + nb0) * 4;
-    const int64_t g_off = (int64_t)8 * p.Cout;                  // floats between k4 = 2g+lh and 2(g+1)+lh
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -176,82 +193,180 @@ __global__ __launch_bounds__(256, 3) void conv3x3_f32_kernel(const ConvParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    auto load_b = [&](int step, f32x4 (&b)[2][2]) {
-        const float *sl = wl + (int64_t)step * slab_stride;
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            b[0][g] = nok0 ? *reinterpret_cast<const f32x4 *>(sl + g * g_off) : z;
-            b[1][g] = nok1 ? *reinterpret_cast<const f32x4 *>(sl + g * g_off + 128) : z;
-        }
-    };
-    auto load_a = [&](const float *pc, int tap, f32x4 (&a)[2][2]) {
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const float *ap = pc + a_lane + (ky * C::PW + kx) * C::PS;
+    auto load_a = [&](const float *pc, int tap_off, f32x4 (&a)[2][2]) {
+        const float *ap = pc + a_lane + tap_off;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int g = 0; g < 2; ++g)
                 a[mt][g] = *reinterpret_cast<const f32x4 *>(ap + (2 * mt * C::STRIDE * C::PW) * C::PS + g * 8);
     };
+    auto mfma32 = [&](const f32x4 (&a)[2][2], const f32x4 (&b)[2][2]) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][g][j], b[nt][g][j], acc[mt][nt], 0, 0, 0);
+    };
 
-    // ---- prologue: chunk 0 patch -> LDS, weights of step 0 -> registers
-    f32x4 bcur[2][2], bnxt[2][2];
-    load_b(0, bcur);
-    for (int e = tid; e < C::NQ; e += 256) store_patch_quad<C>(patch_buf, e, load_patch_quad<C>(p, s, 0, e, iy0, ix0));
-    __syncthreads();
+    if constexpr (FAST) {
+        // ================================================================================ FAST path
+        const unsigned hw = (unsigned)p.H * (unsigned)p.W;
+        const __amdgpu_buffer_rsrc_t rs_cur = make_rsrc(s.cur, hw * p.Cin * 4u);
+        const __amdgpu_buffer_rsrc_t rs_prev = make_rsrc(s.prev ? s.prev : s.cur, s.prev ? hw * s.prev_ps * 4u : 0u);
+        const __amdgpu_buffer_rsrc_t rs_next = make_rsrc(s.next ? s.next : s.cur, s.next ? hw * s.next_ps * 4u : 0u);
+        const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)p.Cin * 9u * p.Cout * 4u);
+        auto chunk_src = [&](int cb) {
+            ChunkSrc c;
+            const int c0 = cb * 16;
+            if (c0 < p.fold)          { c.rs = rs_next; c.ps4 = s.next_ps * 4u; c.soff = (s.next_co + c0) * 4u; }
+            else if (c0 < 2 * p.fold) { c.rs = rs_prev; c.ps4 = s.prev_ps * 4u; c.soff = (s.prev_co + c0 - p.fold) * 4u; }
+            else                      { c.rs = rs_cur;  c.ps4 = p.Cin * 4u;     c.soff = c0 * 4u; }
+            return c;
+        };
 
-    for (int cb = 0; cb < ncb; ++cb) {
-        const float *pcur = patch_buf + (cb & 1) * C::PATCH_FLOATS;
-        float *pnext = patch_buf + ((cb + 1) & 1) * C::PATCH_FLOATS;
-        const bool more_chunks = cb + 1 < ncb;
-        f32x4 acur[2][2], anxt[2][2];
-        load_a(pcur, 0, acur);
-#ifdef BSVD_ABLATE
-        load_a(pcur, 0, anxt);
-        load_b(0, bnxt);
-#endif
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            // (1) global loads for the next step: weights -> registers, 1/9 of the next chunk's patch
-#ifdef BSVD_ABLATE   // timing-only ablation build (results invalid): p.ablate bit0 = no weight loads, bit1 = no patch prefetch, bit2 = no A reads
-            if ((tap < 8 || more_chunks) && !(p.ablate & 1)) load_b(cb * 9 + tap + 1, bnxt);
-            const int ep = tap * C::Q_PER_STEP + tid;
-            const bool do_p = more_chunks && tid < C::Q_PER_STEP && ep < C::NQ && !(p.ablate & 2);
-#else
-            if (tap < 8 || more_chunks) load_b(cb * 9 + tap + 1, bnxt);
-            const int ep = tap * C::Q_PER_STEP + tid;
-            const bool do_p = more_chunks && tid < C::Q_PER_STEP && ep < C::NQ;
-#endif
-            f32x4 preg = {0.f, 0.f, 0.f, 0.f};
-            if (do_p) preg = load_patch_quad<C>(p, s, cb + 1, ep, iy0, ix0);
-            // (2) next tap's A fragments (same patch) while this tap's 32 MFMAs run
-#ifdef BSVD_ABLATE
-            if (tap < 8 && !(p.ablate & 4)) load_a(pcur, tap + 1, anxt);
-#else
-            if (tap < 8) load_a(pcur, tap + 1, anxt);
-#endif
+        // weights: lane's byte offset inside a (chunk, tap) slab; the OOB sentinel masks columns >= Cout
+        const unsigned slab_bytes = 64u * p.Cout;                // 4 k4 rows x Cout x 16 B
+        const unsigned g_bytes = 32u * p.Cout;                   // k4 -> k4 + 2
+        const unsigned vb0 = nb0 < p.Cout ? (unsigned)(lh * p.Cout + nb0) * 16u : BSVD_OOB;
+        const unsigned vb1 = nb0 + 32 < p.Cout ? (unsigned)(lh * p.Cout + nb0 + 32) * 16u : BSVD_OOB;
+        auto load_b = [&](int step, f32x4 (&b)[2][2]) {
+            const unsigned so = (unsigned)step * slab_bytes;
+            b[0][0] = buf_load4(rs_w, vb0, so);
+            b[1][0] = buf_load4(rs_w, vb1, so);
+            b[0][1] = buf_load4(rs_w, vb0, so + g_bytes);
+            b[1][1] = buf_load4(rs_w, vb1, so + g_bytes);
+        };
+
+        // patch slices: thread = (row r3 inside a pass, column, channel quad)
+        const int r3 = tid / C::ROW_ITEMS, rem = tid - r3 * C::ROW_ITEMS;
+        const int pcol = rem >> 2, pq = rem & 3;
+        const bool t_ok = r3 < C::R;
+        const int gx = ix0 + pcol;
+        const bool x_ok = t_ok && gx >= 0 && gx < p.W;
+        const int lds_item = (r3 * C::PW + pcol) * C::PS + pq * 4;            // floats, pass row 0
+        auto slice_load = [&](const ChunkSrc &c, int row0, f32x4 (&v)[C::P]) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
+            for (int i = 0; i < C::P; ++i) {
+                const int prow = row0 + i * C::R + r3;
+                const int gy = iy0 + prow;
+                const bool ok = x_ok && prow < C::PH && gy >= 0 && gy < p.H;
+                const unsigned voff = ok ? (unsigned)(gy * p.W + gx) * c.ps4 + pq * 16u : BSVD_OOB;
+                v[i] = buf_load4(c.rs, voff, c.soff);
+            }
+        };
+        auto slice_store = [&](float *pb, int row0, const f32x4 (&v)[C::P]) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[mt][g][j], bcur[nt][g][j],
-                                                                               acc[mt][nt], 0, 0, 0);
-            // (3) land the prefetched patch slice in the other buffer; rotate registers
-            if (do_p) store_patch_quad<C>(pnext, ep, preg);
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    acur[u][g] = anxt[u][g];
-                    bcur[u][g] = bnxt[u][g];
-                }
+            for (int i = 0; i < C::P; ++i) {
+                const int prow = row0 + i * C::R + r3;
+                if (t_ok && prow < C::PH)
+                    *reinterpret_cast<f32x4 *>(pb + lds_item + (row0 + i * C::R) * (C::PW * C::PS)) = v[i];
+            }
+        };
+
+        // ---- prologue: weights of steps 0 and 1 in flight, chunk 0 patch -> LDS
+        f32x4 b0[2][2], b1[2][2], b2[2][2];
+        load_b(0, b0);
+        load_b(1, b1);
+        {
+            const ChunkSrc c = chunk_src(0);
+            for (int row0 = 0; row0 < C::PH; row0 += C::ROWS_PER_SLICE) {
+                f32x4 v[C::P];
+                slice_load(c, row0, v);
+                slice_store(patch_buf, row0, v);
+            }
         }
-        __syncthreads();   // one barrier per 16-channel chunk (9 taps, 288 MFMAs per wave)
+        __syncthreads();
+
+        const int nsteps = ncb * 9;
+        int step = 0;
+        for (int cb = 0; cb < ncb; ++cb) {
+            const float *pcur = patch_buf + (cb & 1) * C::PATCH_FLOATS;
+            float *pnext = patch_buf + ((cb + 1) & 1) * C::PATCH_FLOATS;
+            // next chunk's source; after the last chunk a zero-size descriptor turns the slice loads into no-ops
+            ChunkSrc cn = chunk_src(cb + 1 < ncb ? cb + 1 : cb);
+            if (cb + 1 >= ncb) cn.rs = make_rsrc(s.cur, 0u);
+            f32x4 s0[C::P], s1[C::P], s2[C::P];
+#pragma unroll
+            for (int i = 0; i < C::P; ++i) s2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int ky = 0; ky < 3; ++ky) {
+                // three taps per trip so that both register rings rotate statically:
+                //   weights  b0 -> b1 -> b2 (filled two steps ahead),  slices  s0 -> s1 -> s2 (stored one step later)
+#define BSVD_TAP(KX, BCUR, BFILL, SNEW, SOLD)                                                                  \
+                {                                                                                              \
+                    const int tap = ky * 3 + (KX);                                                             \
+                    f32x4 a[2][2];                                                                             \
+                    load_a(pcur, (ky * C::PW + (KX)) * C::PS, a);                                              \
+                    load_b(step + 2 < nsteps ? step + 2 : nsteps - 1, BFILL);                                  \
+                    slice_load(cn, tap * C::ROWS_PER_SLICE, SNEW);   /* rows >= PH: OOB, zeros, never stored */ \
+                    mfma32(a, BCUR);                                                                           \
+                    if (tap >= 1 && tap <= C::NSLICE) slice_store(pnext, (tap - 1) * C::ROWS_PER_SLICE, SOLD); \
+                    ++step;                                                                                    \
+                }
+                BSVD_TAP(0, b0, b2, s0, s2)
+                BSVD_TAP(1, b1, b0, s1, s0)
+                BSVD_TAP(2, b2, b1, s2, s1)
+#undef BSVD_TAP
+            }
+            __syncthreads();   // one barrier per 16-channel chunk (9 taps, 288 MFMAs per wave)
+        }
+    } else {
+        // ============================================================================= GENERIC path
+        const int64_t slab_stride = (int64_t)16 * p.Cout;           // floats per (chunk, tap) weight slab
+        const bool nok0 = nb0 < p.Cout, nok1 = nb0 + 32 < p.Cout;
+        const float *wl = p.w + ((int64_t)lh * p.Cout + nb0) * 4;
+        const int64_t g_off = (int64_t)8 * p.Cout;
+        auto load_b = [&](int step, f32x4 (&b)[2][2]) {
+            const float *sl = wl + (int64_t)step * slab_stride;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                b[0][g] = nok0 ? *reinterpret_cast<const f32x4 *>(sl + g * g_off) : z;
+                b[1][g] = nok1 ? *reinterpret_cast<const f32x4 *>(sl + g * g_off + 128) : z;
+            }
+        };
+        f32x4 bcur[2][2], bnxt[2][2];
+        load_b(0, bcur);
+        for (int e = tid; e < C::NQ; e += 256) store_patch_quad<C>(patch_buf, e, load_patch_quad<C>(p, s, 0, e, iy0, ix0));
+        __syncthreads();
+
+        for (int cb = 0; cb < ncb; ++cb) {
+            const float *pcur = patch_buf + (cb & 1) * C::PATCH_FLOATS;
+            float *pnext = patch_buf + ((cb + 1) & 1) * C::PATCH_FLOATS;
+            const bool more_chunks = cb + 1 < ncb;
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap < 8 || more_chunks) load_b(cb * 9 + tap + 1, bnxt);
+                f32x4 preg[C::QG];
+#pragma unroll
+                for (int i = 0; i < C::QG; ++i) {
+                    const int ep = tap * C::Q_PER_STEP + tid + i * 256;
+                    const bool do_p = more_chunks && tid + i * 256 < C::Q_PER_STEP && ep < C::NQ;
+                    preg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (do_p) preg[i] = load_patch_quad<C>(p, s, cb + 1, ep, iy0, ix0);
+                }
+                const int ky = tap / 3, kx = tap - ky * 3;
+                f32x4 a[2][2];
+                load_a(pcur, (ky * C::PW + kx) * C::PS, a);
+                mfma32(a, bcur);
+#pragma unroll
+                for (int i = 0; i < C::QG; ++i) {
+                    const int ep = tap * C::Q_PER_STEP + tid + i * 256;
+                    const bool do_p = more_chunks && tid + i * 256 < C::Q_PER_STEP && ep < C::NQ;
+                    if (do_p) store_patch_quad<C>(pnext, ep, preg[i]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) bcur[u][g] = bnxt[u][g];
+            }
+            __syncthreads();
+        }
     }
 
     // ---- epilogue.  C/D layout of 32x32 MFMA: col (n) = lane&31, row (m) = (r&3) + 8*(r>>2) + 4*(lane>>5);
@@ -289,7 +404,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_f32_kernel(const ConvParams p)
     }
 }
 
-template <class C>
+template <class C, bool FAST>
 static int launch_cfg(const ConvParams &pin, hipStream_t stream)
 {
     ConvParams p = pin;
@@ -300,13 +415,23 @@ static int launch_cfg(const ConvParams &pin, hipStream_t stream)
     if (nblk <= 0 || nblk > 0x7fffffff) { set_error("bsvd_conv3x3: grid of %lld workgroups", (long long)nblk); return -1; }
     static bool attr_done = false;   // benign race: the call is idempotent
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_f32_kernel<C>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_f32_kernel<C, FAST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv3x3_f32_kernel<C>, dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv3x3_f32_kernel<C, FAST>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, stream, p);
     return (int)hipGetLastError();
+}
+
+template <class C>
+static int launch_pick(const ConvParams &p, hipStream_t stream)
+{
+    // FAST needs: 16-B aligned vector gather (vec_ok), single-source 16-channel chunks (fold % 16 == 0) and
+    // 32-bit byte offsets inside one frame / the packed weights.  (ablate == 8: timing builds force GENERIC.)
+    const bool fast = p.vec_ok && (p.fold & 15) == 0 && (int64_t)p.H * p.W * p.Cin * 4 < 0x7fffffffLL &&
+                      (int64_t)p.Cin * 9 * p.Cout * 4 < 0x7fffffffLL && p.ablate != 8;
+    return fast ? launch_cfg<C, true>(p, stream) : launch_cfg<C, false>(p, stream);
 }
 
 int launch_conv3x3_f32(const ConvParams &p, int stride, hipStream_t stream)
@@ -314,8 +439,8 @@ int launch_conv3x3_f32(const ConvParams &p, int stride, hipStream_t stream)
     // Cout <= 64 (the 540x960-level layers of bsvd_c64): 256 px x 64 ch tiles; wider layers: 128 px x 128 ch.
     // Stride 2 always takes the 128 x 128 tile (its 17x33 input patch is what bounds LDS).
     if (stride == 1)
-        return p.Cout > 64 ? launch_cfg<ConvCfg<8, 2, 2, 1>>(p, stream) : launch_cfg<ConvCfg<16, 4, 1, 1>>(p, stream);
-    return launch_cfg<ConvCfg<8, 2, 2, 2>>(p, stream);
+        return p.Cout > 64 ? launch_pick<ConvCfg<8, 2, 2, 1>>(p, stream) : launch_pick<ConvCfg<16, 4, 1, 1>>(p, stream);
+    return launch_pick<ConvCfg<8, 2, 2, 2>>(p, stream);
 }
 
 }  // namespace bsvd
