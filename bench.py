@@ -66,8 +66,13 @@ class LaunchTimer:
         e0.record()
         y = self._orig(sp, x, *a, **k)
         e1.record()
-        T, Hh, Ww, _ = x.shape
-        self.records.append((sp, T, Hh, Ww, e0, e1))
+        if k.get("x_planar"):
+            T, _, Hh, Ww = x.shape
+            name = "head_kernel"
+        else:
+            T, Hh, Ww, _ = x.shape
+            name = "tail_kernel" if k.get("y_planar") is not None else self.variant(sp)
+        self.records.append((sp, T, Hh, Ww, e0, e1, name))
         return y
 
     def detach(self):
@@ -81,9 +86,9 @@ class LaunchTimer:
 
     def summary(self):
         agg = {}
-        for sp, T, Hh, Ww, e0, e1 in self.records:
+        for sp, T, Hh, Ww, e0, e1, name in self.records:
             ms = e0.elapsed_time(e1)
-            d = agg.setdefault(self.variant(sp), {"ms": 0.0, "flop": 0.0, "launches": 0})
+            d = agg.setdefault(name, {"ms": 0.0, "flop": 0.0, "launches": 0})
             d["ms"] += ms
             d["flop"] += 2.0 * sp.macs(Hh, Ww) * T
             d["launches"] += 1

@@ -9,6 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbsvd_hip.so")
 
+ABI_VERSION = 2
 BSVD_F32, BSVD_F16 = 0, 1
 ACT = {"none": 0, "relu": 1, "relu6": 2}
 EPI_PLAIN, EPI_PS_ADD, EPI_RESID = 0, 1, 2
@@ -40,6 +41,8 @@ class BsvdConvArgs(ctypes.Structure):
         ("Cin", ctypes.c_int32), ("Cout", ctypes.c_int32),
         ("stride", ctypes.c_int32),
         ("act", ctypes.c_int32), ("epilogue", ctypes.c_int32), ("dtype", ctypes.c_int32),
+        ("x_planar_ch", ctypes.c_int32), ("y_planar_ch", ctypes.c_int32), ("y_clamp", ctypes.c_int32),
+        ("y_lo", ctypes.c_float), ("y_hi", ctypes.c_float),
     ]
 
 
@@ -79,8 +82,8 @@ def load():
     lib.bsvd_nhwc_to_nchw.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp]
     lib.bsvd_halo_pack.restype = ctypes.c_int
     lib.bsvd_halo_pack.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
-    if lib.bsvd_abi_version() != 1:
-        raise BsvdLibraryError("libbsvd_hip.so ABI version %d, expected 1" % lib.bsvd_abi_version())
+    if lib.bsvd_abi_version() != ABI_VERSION:
+        raise BsvdLibraryError("libbsvd_hip.so ABI version %d, expected %d" % (lib.bsvd_abi_version(), ABI_VERSION))
     if lib.bsvd_conv_args_size() != ctypes.sizeof(BsvdConvArgs):
         raise BsvdLibraryError("BsvdConvArgs layout mismatch: library %d bytes, binding %d bytes"
                                % (lib.bsvd_conv_args_size(), ctypes.sizeof(BsvdConvArgs)))

@@ -14,7 +14,7 @@ import torch.nn as nn
 from . import checkpoint
 from .netspec import make_netspec
 from .registry import register_arch
-from .schedule import StreamPipeline, bsvd_clip
+from .schedule import StreamPipeline, bsvd_clip, planar_ok
 
 
 class _Slots(nn.Module):
@@ -136,14 +136,18 @@ class BSVD(nn.Module):
                 self._pipe = StreamPipeline(self.net)
             xin = None
             out_dtype = torch.float32
+            pin, pout = planar_ok(ex, self.net)
             if x is not None:
                 out_dtype = x.dtype if x.dtype in (torch.float16, torch.bfloat16) else torch.float32
-                xin = ex.to_nhwc(x.to(device=dev, dtype=torch.float32), self.net.temp1["inc0"].cin_pad)
+                xin = x.to(device=dev, dtype=torch.float32).contiguous()
+                if not pin:
+                    xin = ex.to_nhwc(xin, self.net.temp1["inc0"].cin_pad)
                 self._last_dtype = out_dtype
-            y = self._pipe.feed(ex, xin)
+            y = self._pipe.feed(ex, xin, x_planar=pin, y_planar=(self.net.out_ch, self.clamp) if pout else None)
             if y is None:
                 return None
-            y = ex.to_nchw(y, self.net.out_ch, self.clamp)
+            if not pout:
+                y = ex.to_nchw(y, self.net.out_ch, self.clamp)
             return y.to(getattr(self, "_last_dtype", out_dtype))
 
     def streaming_forward(self, input_seq):
@@ -171,9 +175,15 @@ class BSVD(nn.Module):
         with torch.no_grad(), torch.cuda.device(dev):
             ex = self._executor(dev)
             out_dtype = frames.dtype if frames.dtype in (torch.float16, torch.bfloat16) else torch.float32
-            x = ex.to_nhwc(frames.to(device=dev, dtype=torch.float32), self.net.temp1["inc0"].cin_pad)
-            y = bsvd_clip(ex, self.net, x, halo_fn)
-            return ex.to_nchw(y, self.net.out_ch, self.clamp).to(out_dtype)
+            pin, pout = planar_ok(ex, self.net)
+            x = frames.to(device=dev, dtype=torch.float32).contiguous()
+            if not pin:
+                x = ex.to_nhwc(x, self.net.temp1["inc0"].cin_pad)
+            y = bsvd_clip(ex, self.net, x, halo_fn, x_planar=pin,
+                          y_planar=(self.net.out_ch, self.clamp) if pout else None)
+            if not pout:
+                y = ex.to_nchw(y, self.net.out_ch, self.clamp)
+            return y.to(out_dtype)
 
     def forward(self, input, noise_map=None):
         # N, F, C, H, W -> (N*F, C, H, W): like the reference, N>1 is one long clip

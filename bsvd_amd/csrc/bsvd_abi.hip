@@ -170,6 +170,18 @@ int bsvd_conv3x3(const BsvdConvArgs *a, void *stream)
     if (const char *e = getenv("BSVD_ABLATE")) p.ablate = atoi(e);
 #endif
     if ((((uintptr_t)a->w_packed) & 15) != 0) { set_error("bsvd_conv3x3: w_packed must be 16-byte aligned"); return -13; }
+    if (a->x_planar_ch > 0 || a->y_planar_ch > 0) {
+        if (a->x_planar_ch > 0 && a->y_planar_ch > 0) { set_error("bsvd_conv3x3: x_planar_ch and y_planar_ch are exclusive"); return -16; }
+        if (a->stride != 1 || a->fold != 0) { set_error("bsvd_conv3x3: planar edge layers need stride 1 and fold 0"); return -16; }
+        if ((int64_t)a->H * a->W * (a->Cin > a->Cout ? a->Cin : a->Cout) >= 0x7fffffffLL) { set_error("bsvd_conv3x3: frame too large for the edge kernels"); return -16; }
+        if (a->x_planar_ch > 0) {
+            if (a->Cin != 16 || a->epilogue != BSVD_EPI_PLAIN) { set_error("bsvd_conv3x3: planar input needs Cin == 16 (padded) and the PLAIN epilogue"); return -16; }
+            return launch_head_f32(p, a->x_planar_ch, (hipStream_t)stream);
+        }
+        if (a->Cout != 16 || a->epilogue == BSVD_EPI_PS_ADD) { set_error("bsvd_conv3x3: planar output needs Cout == 16 (padded) and PLAIN/RESID"); return -16; }
+        if (a->epilogue == BSVD_EPI_RESID && a->resid_ch > a->y_planar_ch) { set_error("bsvd_conv3x3: resid_ch > y_planar_ch"); return -16; }
+        return launch_tail_f32(p, a->y_planar_ch, a->y_clamp, a->y_lo, a->y_hi, (hipStream_t)stream);
+    }
     return launch_conv3x3_f32(p, a->stride, (hipStream_t)stream);
 }
 

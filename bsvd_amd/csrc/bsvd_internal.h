@@ -30,4 +30,8 @@ void set_error(const char *fmt, ...);
 // conv3x3_f32_mfma.hip
 int launch_conv3x3_f32(const ConvParams &p, int stride, hipStream_t stream);
 
+// conv3x3_edge_f32.hip
+int launch_head_f32(const ConvParams &p, int cin_real, hipStream_t stream);
+int launch_tail_f32(const ConvParams &p, int cout_real, int do_clamp, float lo, float hi, hipStream_t stream);
+
 }  // namespace bsvd

@@ -1,0 +1,207 @@
+// conv3x3_edge_f32.hip -- the two bandwidth-bound edge layers of the BSVD network (exact fp32, VALU).
+//
+// layer 1 (Cin = 4 -> 64, K = 36) and layer 32 (64 -> Cout = 3) are < 0.4 % of the FLOPs but
+// padding them to MFMA tiles costs ~5 % of the clip time, and they sit next to the NCHW <-> NHWC layout change.
+// So they get dedicated kernels that also absorb that change:
+//
+//   head_kernel<CIN>  : x planar NCHW [f][CIN][H][W] (the caller's tensor, bsvd_arch.py:494-499)
+//                       -> y NHWC [f][H][W][Cout_pad], bias + act.              (InputCvBlock conv 0, :208-209)
+//   tail_kernel<COUT> : x NHWC [f][H][W][Cin_pad] -> y planar NCHW [f][COUT][H][W], bias (+act),
+//                       residual y[c] = base[c] - y[c] (c < resid_ch) and optional clamp.
+//                                                   (OutputCvBlock conv 3 :298, none_minus :408-414, clamp of
+//                                                    validation_seq_infer.py:24, torch.cat :552)
+//
+// Both read the SAME packed weight layout as the MFMA kernel ([Cin_pad/16][9][4][Cout_pad][4]); weights are
+// wave-uniform and travel through the scalar cache into SGPR operands of v_fma_f32.  Accumulation order is a plain
+// fp32 fmaf chain over (chunk, tap, channel) -- exact fp32 like the MFMA path.
+#include "bsvd_internal.h"
+
+namespace bsvd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Weights/bias are read-only for the whole launch and indexed wave-uniformly: reading them through the constant
+// address space lets the compiler use scalar loads (SGPR operands) even with stores in the same loop.
+typedef const __attribute__((address_space(4))) float *cfloat_p;
+__device__ __forceinline__ cfloat_p as_const(const float *p) { return (cfloat_p)(uintptr_t)p; }
+
+__device__ __forceinline__ float edge_act(float v, int act)
+{
+    if (act >= BSVD_ACT_RELU) v = fmaxf(v, 0.f);
+    if (act == BSVD_ACT_RELU6) v = fminf(v, 6.f);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// head: thread = one pixel; workgroup = 64 x 4 pixels (a wave reads 64 consecutive x of one row: coalesced planes)
+template <int CIN>
+__global__ __launch_bounds__(256) void head_kernel(const ConvParams p)
+{
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int ntx = (p.W + 63) >> 6, nty = (p.H + 3) >> 2;
+    int bid = blockIdx.x;
+    const int bx = bid % ntx; bid /= ntx;
+    const int by = bid % nty;
+    const int f = bid / nty;
+    const int ox = bx * 64 + tx, oy = by * 4 + ty;
+    const bool live = ox < p.W && oy < p.H;
+
+    const float *xin = p.x + (int64_t)f * p.x_fs;
+    const int64_t plane = (int64_t)p.H * p.W;
+    float in[9][CIN];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            const bool ok = live && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) in[ky * 3 + kx][c] = ok ? xin[c * plane + (int64_t)iy * p.W + ix] : 0.f;
+        }
+
+    float *yout = p.y + (int64_t)f * p.y_fs + ((int64_t)oy * p.W + ox) * p.Cout;
+    const cfloat_p w = as_const(p.w);
+    const cfloat_p bias = as_const(p.bias);
+    for (int nb = 0; nb < p.Cout; nb += 16) {            // wave-uniform: weights below come through the scalar cache
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = bias ? bias[nb + j] : 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const cfloat_p wt = w + ((int64_t)(tap * 4) * p.Cout + nb) * 4;     // [k4 = 0][n = nb..nb+15][4]
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] = fmaf(in[tap][c], wt[j * 4 + c], acc[j]);
+        }
+        if (live) {
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = edge_act(acc[j4 * 4 + j], p.act);
+                *reinterpret_cast<f32x4 *>(yout + nb + j4 * 4) = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// tail: workgroup = 16 x 16 pixels; per 16-channel chunk the 18 x 18 patch goes through LDS, thread = one pixel
+struct TailCfg {
+    static constexpr int T = 16, PWD = 18, PS = 20, NP = PWD * PWD, NQ = NP * 4;
+    static constexpr int LDS_BYTES = 2 * NP * PS * 4;
+};
+
+template <int COUT>
+__global__ __launch_bounds__(256) void tail_kernel(const ConvParams p, int y_planar_ch, int do_clamp, float lo, float hi)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using C = TailCfg;
+    const int tid = threadIdx.x;
+    const int px = tid & 15, py = tid >> 4;
+    const int ntx = (p.W + 15) >> 4, nty = (p.H + 15) >> 4;
+    int bid = blockIdx.x;
+    const int bx = bid % ntx; bid /= ntx;
+    const int by = bid % nty;
+    const int f = bid / nty;
+    const int ox0 = bx * 16, oy0 = by * 16;
+    const float *xin = p.x + (int64_t)f * p.x_fs;
+    const int ncb = p.Cin >> 4;
+
+    // staging items of this thread: e = tid + i*256 -> (patch pixel, channel quad); precomputed once
+    constexpr int NI = (C::NQ + 255) / 256;
+    int g_off[NI], l_off[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e = tid + i * 256;
+        const int pix = e >> 2, q = e & 3;
+        const int r = pix / C::PWD, c = pix - r * C::PWD;
+        const int iy = oy0 + r - 1, ix = ox0 + c - 1;
+        const bool ok = e < C::NQ && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        g_off[i] = ok ? (iy * p.W + ix) * p.Cin + q * 4 : -1;      // < 2^31 elements per frame (checked by the host)
+        l_off[i] = e < C::NQ ? pix * C::PS + q * 4 : -1;
+    }
+    auto stage_load = [&](int cb, f32x4 (&v)[NI]) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (g_off[i] >= 0) v[i] = *reinterpret_cast<const f32x4 *>(xin + g_off[i] + cb * 16);
+        }
+    };
+    auto stage_store = [&](float *buf, const f32x4 (&v)[NI]) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (l_off[i] >= 0) *reinterpret_cast<f32x4 *>(buf + l_off[i]) = v[i];
+    };
+
+    float acc[COUT];
+#pragma unroll
+    for (int n = 0; n < COUT; ++n) acc[n] = 0.f;
+    const cfloat_p w = as_const(p.w);
+
+    f32x4 st[NI];
+    stage_load(0, st);
+    stage_store(smem, st);
+    __syncthreads();
+    for (int cb = 0; cb < ncb; ++cb) {
+        const float *cur = smem + (cb & 1) * (C::NP * C::PS);
+        if (cb + 1 < ncb) stage_load(cb + 1, st);          // in flight during this chunk's 9 taps
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const float *ap = cur + ((py + ky) * C::PWD + (px + kx)) * C::PS;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(ap + k4 * 4);
+                const cfloat_p wt = w + (((int64_t)(cb * 9 + tap) * 4 + k4) * p.Cout) * 4;   // [n][4], n = 0..COUT-1
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int n = 0; n < COUT; ++n) acc[n] = fmaf(a[j], wt[n * 4 + j], acc[n]);
+            }
+        }
+        if (cb + 1 < ncb) stage_store(smem + ((cb + 1) & 1) * (C::NP * C::PS), st);
+        __syncthreads();
+    }
+
+    const int ox = ox0 + px, oy = oy0 + py;
+    if (ox < p.W && oy < p.H) {
+        const int64_t opix = (int64_t)oy * p.W + ox;
+        const int64_t plane = (int64_t)p.H * p.W;
+#pragma unroll
+        for (int n = 0; n < COUT; ++n) {
+            if (n >= y_planar_ch) break;
+            float v = edge_act(acc[n] + (p.bias ? as_const(p.bias)[n] : 0.f), p.act);
+            if (p.epilogue == BSVD_EPI_RESID && n < p.resid_ch)
+                v = p.extra[(int64_t)f * p.extra_fs + opix * p.extra_ps + (int64_t)n * p.extra_cs] - v;
+            if (do_clamp) v = fminf(fmaxf(v, lo), hi);
+            p.y[(int64_t)f * p.y_fs + n * plane + opix] = v;
+        }
+    }
+}
+
+int launch_head_f32(const ConvParams &p, int cin_real, hipStream_t stream)
+{
+    const int64_t nblk = (int64_t)p.frames * ((p.H + 3) / 4) * ((p.W + 63) / 64);
+    if (nblk <= 0 || nblk > 0x7fffffff) { set_error("bsvd_conv3x3(head): grid of %lld workgroups", (long long)nblk); return -1; }
+    if (cin_real == 4) hipLaunchKernelGGL(head_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, stream, p);
+    else if (cin_real == 3) hipLaunchKernelGGL(head_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, stream, p);
+    else { set_error("bsvd_conv3x3: planar input supports 3 or 4 channels, got %d", cin_real); return -14; }
+    return (int)hipGetLastError();
+}
+
+int launch_tail_f32(const ConvParams &p, int cout_real, int do_clamp, float lo, float hi, hipStream_t stream)
+{
+    const int64_t nblk = (int64_t)p.frames * ((p.H + 15) / 16) * ((p.W + 15) / 16);
+    if (nblk <= 0 || nblk > 0x7fffffff) { set_error("bsvd_conv3x3(tail): grid of %lld workgroups", (long long)nblk); return -1; }
+    if (cout_real < 1 || cout_real > 4) { set_error("bsvd_conv3x3: planar output supports 1..4 channels, got %d", cout_real); return -15; }
+    if (cout_real == 3)
+        hipLaunchKernelGGL(tail_kernel<3>, dim3((unsigned)nblk), dim3(256), TailCfg::LDS_BYTES, stream, p, cout_real,
+                           do_clamp, lo, hi);
+    else
+        hipLaunchKernelGGL(tail_kernel<4>, dim3((unsigned)nblk), dim3(256), TailCfg::LDS_BYTES, stream, p, cout_real,
+                           do_clamp, lo, hi);
+    return (int)hipGetLastError();
+}
+
+}  // namespace bsvd

@@ -93,21 +93,41 @@ class HipExecutor:
         return out
 
     # -- the fused layer -------------------------------------------------------------------------
-    def conv(self, sp, x, halo_prev=None, halo_next=None, extra=None, extra_pstride=0, extra_cstride=1):
-        T, H, W, cin_pad = x.shape
-        if cin_pad != sp.cin_pad:
-            raise ValueError("%s: input has %d channels, layer expects %d" % (sp.key, cin_pad, sp.cin_pad))
+    planar_io = True      # the edge kernels read planar NCHW input / write planar NCHW output directly
+
+    def conv(self, sp, x, halo_prev=None, halo_next=None, extra=None, extra_pstride=0, extra_cstride=1,
+             x_planar=False, y_planar=None):
+        """x_planar: x is the caller's planar [T,C,H,W] tensor (first layer).  y_planar=(channels, clamp|None):
+        write the planar [T,channels,H,W] result directly (last layer)."""
+        a = _lib.BsvdConvArgs()
         if not x.is_contiguous():
-            raise ValueError("%s: input must be contiguous NHWC" % sp.key)
+            raise ValueError("%s: input must be contiguous" % sp.key)
+        if x_planar:
+            T, C, H, W = x.shape
+            if C != sp.cin or sp.cin_pad != 16 or sp.stride != 1 or sp.tsm:
+                raise ValueError("%s: planar input needs a plain stride-1 layer with <= 4 input channels" % sp.key)
+            a.x_planar_ch = C
+            a.x_frame_stride = C * H * W
+        else:
+            T, H, W, cin_pad = x.shape
+            if cin_pad != sp.cin_pad:
+                raise ValueError("%s: input has %d channels, layer expects %d" % (sp.key, cin_pad, sp.cin_pad))
+            a.x_frame_stride = H * W * cin_pad
         Ho, Wo = (H - 1) // sp.stride + 1, (W - 1) // sp.stride + 1
-        if sp.epilogue == EPI_PS_ADD:
+        if y_planar is not None:
+            yc, clamp = y_planar
+            if sp.cout_pad != 16 or yc != sp.cout or sp.stride != 1 or sp.tsm or sp.epilogue == EPI_PS_ADD:
+                raise ValueError("%s: planar output needs a plain stride-1 layer with <= 4 output channels" % sp.key)
+            y = torch.empty((T, yc, H, W), dtype=torch.float32, device=x.device)
+            a.y_planar_ch = yc
+            if clamp is not None:
+                a.y_clamp, a.y_lo, a.y_hi = 1, float(clamp[0]), float(clamp[1])
+        elif sp.epilogue == EPI_PS_ADD:
             y = torch.empty((T, 2 * Ho, 2 * Wo, sp.cout_pad // 4), dtype=torch.float32, device=x.device)
         else:
             y = torch.empty((T, Ho, Wo, sp.cout_pad), dtype=torch.float32, device=x.device)
         wp, bp = self.packed.tensors[sp.key]
-        a = _lib.BsvdConvArgs()
         a.x = x.data_ptr()
-        a.x_frame_stride = H * W * cin_pad
         if sp.tsm:
             a.fold = sp.fold
             if halo_prev is not None:

@@ -21,9 +21,25 @@ Halo = namedtuple("Halo", ["t", "pstride", "coff"])
 
 
 # ------------------------------------------------------------------------------------------ clip mode
-def denblock_clip(ex, S, x, halo_fn=None):
-    """One DenBlock over a clip.  x: [T,H,W,cin_pad] NHWC.  halo_fn(spec, x) -> (Halo|None, Halo|None)
-    supplies the neighbour shards' boundary slices when the clip is a frame-window shard."""
+def _base_strides(x, x_planar):
+    """(pixel stride, channel stride) of the residual base tensor: NHWC [T,H,W,C] or planar [T,C,H,W]."""
+    if x_planar:
+        return 1, x.shape[-2] * x.shape[-1]
+    return x.shape[-1], 1
+
+
+def planar_ok(ex, net):
+    """Can the clip's planar NCHW input / output be consumed / produced directly by the edge layers?"""
+    if not getattr(ex, "planar_io", False):
+        return False, False
+    first, last = net.temp1["inc0"], net.temp2["out3"]
+    return (first.cin in (3, 4) and first.cin_pad == 16), (last.cout <= 4 and last.cout_pad == 16)
+
+
+def denblock_clip(ex, S, x, halo_fn=None, x_planar=False, y_planar=None):
+    """One DenBlock over a clip.  x: [T,H,W,cin_pad] NHWC (or planar [T,C,H,W] with x_planar).
+    halo_fn(spec, x) -> (Halo|None, Halo|None) supplies the neighbour shards' boundary slices when the clip
+    is a frame-window shard.  y_planar=(channels, clamp) makes the last layer write planar NCHW."""
 
     def tsm(name, v):
         hp = hn = None
@@ -31,7 +47,7 @@ def denblock_clip(ex, S, x, halo_fn=None):
             hp, hn = halo_fn(S[name], v)
         return ex.conv(S[name], v, halo_prev=hp, halo_next=hn)
 
-    a = ex.conv(S["inc0"], x)
+    a = ex.conv(S["inc0"], x, x_planar=True) if x_planar else ex.conv(S["inc0"], x)
     x0 = ex.conv(S["inc3"], a)
     del a
     d = ex.conv(S["down0"], x0)
@@ -48,12 +64,17 @@ def denblock_clip(ex, S, x, halo_fn=None):
     del v, x0
     o = ex.conv(S["out0"], w)
     del w
-    return ex.conv(S["out3"], o, extra=x, extra_pstride=x.shape[-1])      # residual vs. the block input
+    eps, ecs = _base_strides(x, x_planar)                                 # residual vs. the block input
+    if y_planar is not None:
+        return ex.conv(S["out3"], o, extra=x, extra_pstride=eps, extra_cstride=ecs, y_planar=y_planar)
+    return ex.conv(S["out3"], o, extra=x, extra_pstride=eps, extra_cstride=ecs)
 
 
-def bsvd_clip(ex, net, x, halo_fn=None):
-    y = denblock_clip(ex, net.temp1, x, halo_fn)
-    return denblock_clip(ex, net.temp2, y, halo_fn)
+def bsvd_clip(ex, net, x, halo_fn=None, x_planar=False, y_planar=None):
+    """x: NHWC-padded clip, or the planar [T,C,H,W] input when x_planar; returns NHWC-padded output, or the
+    planar [T,out_ch,H,W] tensor when y_planar=(out_ch, clamp)."""
+    y = denblock_clip(ex, net.temp1, x, halo_fn, x_planar=x_planar)
+    return denblock_clip(ex, net.temp2, y, halo_fn, y_planar=y_planar)
 
 
 # ---------------------------------------------------------------------------------------- stream mode
@@ -125,10 +146,12 @@ class _DenBlockStream:
     def _pair(self, ex, a, b, v):
         return self.stage[b].feed(ex, self.stage[a].feed(ex, v))
 
-    def feed(self, ex, x):
+    def feed(self, ex, x, x_planar=False, y_planar=None):
         S = self.S
         self.skip_in.push(x)
-        x0 = None if x is None else ex.conv(S["inc3"], ex.conv(S["inc0"], x))
+        x0 = None
+        if x is not None:
+            x0 = ex.conv(S["inc3"], ex.conv(S["inc0"], x, x_planar=True) if x_planar else ex.conv(S["inc0"], x))
         self.skip_x0.push(x0)
         d = None if x0 is None else ex.conv(S["down0"], x0)
         x1 = self._pair(ex, "d0c1", "d0c2", d)
@@ -144,7 +167,11 @@ class _DenBlockStream:
         base = self.skip_in.pop_if(w)
         if w is None:
             return None
-        return ex.conv(S["out3"], ex.conv(S["out0"], w), extra=base, extra_pstride=base.shape[-1])
+        eps, ecs = _base_strides(base, x_planar)
+        o = ex.conv(S["out0"], w)
+        if y_planar is not None:
+            return ex.conv(S["out3"], o, extra=base, extra_pstride=eps, extra_cstride=ecs, y_planar=y_planar)
+        return ex.conv(S["out3"], o, extra=base, extra_pstride=eps, extra_cstride=ecs)
 
 
 class StreamPipeline:
@@ -163,5 +190,5 @@ class StreamPipeline:
         self.t1.clear()
         self.t2.clear()
 
-    def feed(self, ex, x):
-        return self.t2.feed(ex, self.t1.feed(ex, x))
+    def feed(self, ex, x, x_planar=False, y_planar=None):
+        return self.t2.feed(ex, self.t1.feed(ex, x, x_planar=x_planar), y_planar=y_planar)

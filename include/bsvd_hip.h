@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BSVD_ABI_VERSION 1
+#define BSVD_ABI_VERSION 2
 
 enum { BSVD_F32 = 0, BSVD_F16 = 1 };                       /* dtype                                  */
 enum { BSVD_ACT_NONE = 0, BSVD_ACT_RELU = 1, BSVD_ACT_RELU6 = 2 }; /* get_act_function, bsvd_arch.py:185-192 */
@@ -80,6 +80,14 @@ typedef struct BsvdConvArgs {
     int32_t Cin, Cout;          /* padded channel counts: Cin % 16 == 0, Cout % 16 == 0 (PS_ADD: Cout % 64 == 0) */
     int32_t stride;             /* 1 or 2                                                            */
     int32_t act, epilogue, dtype;
+    /* Clip entry/exit fused into the edge layers (optional; 0 = plain NHWC as described above):
+     *   x_planar_ch > 0: x is the caller's planar tensor [frames][x_planar_ch][H][W] fp32 (3 or 4 channels,
+     *                    BSVD.forward's reshaped input, bsvd_arch.py:494-499); needs Cin == 16, stride 1, fold 0, PLAIN.
+     *   y_planar_ch > 0: y is planar [frames][y_planar_ch][H][W] fp32 (1..4 channels, the tensor torch.cat(out_seq)
+     *                    returns, :552); needs Cout == 16, stride 1, fold 0, PLAIN or RESID; y_clamp != 0 additionally
+     *                    clamps to [y_lo, y_hi] (the callers' torch.clamp, validation_seq_infer.py:24). */
+    int32_t x_planar_ch, y_planar_ch, y_clamp;
+    float y_lo, y_hi;
 } BsvdConvArgs;
 
 int bsvd_abi_version(void);

@@ -40,13 +40,21 @@ class OracleExecutor:
     def halo_pack(self, frame, c0, n):
         return frame[..., c0:c0 + n].contiguous()
 
-    def conv(self, sp, x, halo_prev=None, halo_next=None, extra=None, extra_pstride=0, extra_cstride=1):
+    planar_io = True
+
+    def conv(self, sp, x, halo_prev=None, halo_next=None, extra=None, extra_pstride=0, extra_cstride=1,
+             x_planar=False, y_planar=None):
         self.launches += 1
         self.log.append(sp.key)
-        T, H, W, cp = x.shape
-        assert cp == sp.cin_pad, (sp.key, cp, sp.cin_pad)
-        assert float(x[..., sp.cin:].abs().max()) == 0.0 if cp > sp.cin else True, "padded input channels must be zero"
-        v = x[..., :sp.cin].permute(0, 3, 1, 2).contiguous()       # [T,cin,H,W]
+        if x_planar:
+            T, C, H, W = x.shape
+            assert C == sp.cin and sp.cin_pad == 16
+            v = x.contiguous()
+        else:
+            T, H, W, cp = x.shape
+            assert cp == sp.cin_pad, (sp.key, cp, sp.cin_pad)
+            assert float(x[..., sp.cin:].abs().max()) == 0.0 if cp > sp.cin else True, "padded input channels must be zero"
+            v = x[..., :sp.cin].permute(0, 3, 1, 2).contiguous()       # [T,cin,H,W]
         if sp.tsm:
             fold = sp.fold
             g = v.clone()
@@ -85,4 +93,10 @@ class OracleExecutor:
             k = min(3, sp.cout)
             e = torch.as_strided(extra.reshape(-1), (T, Ho * Wo, k), (extra[0].numel(), extra_pstride, extra_cstride))
             out[..., :k] = e.reshape(T, Ho, Wo, k) - out[..., :k]
+        if y_planar is not None:
+            yc, clamp = y_planar
+            assert yc == sp.cout
+            out = out[..., :yc].permute(0, 3, 1, 2).contiguous()
+            if clamp is not None:
+                out = out.clamp(clamp[0], clamp[1])
         return out

@@ -31,7 +31,7 @@ def test_header_symbols_exported():
 def test_struct_layout_matches_header():
     from bsvd_amd import _lib
     lib = _lib.load()
-    assert lib.bsvd_abi_version() == 1
+    assert lib.bsvd_abi_version() == _lib.ABI_VERSION
     lib.bsvd_conv_args_size.restype = ctypes.c_int
     assert lib.bsvd_conv_args_size() == ctypes.sizeof(_lib.BsvdConvArgs)
 

@@ -95,6 +95,46 @@ def test_layer_vs_oracle(cin, cout, stride, tsm, act, epi, T, H, W):
         assert maxabs(got.cpu().numpy(), want.numpy()) < TOL
 
 
+EDGE_CASES = [
+    # kind, cin, cout, act, T, H, W
+    ("head", 4, 64, "relu6", 2, 21, 70),
+    ("head", 3, 30, "relu", 1, 9, 130),
+    ("head", 4, 32, "none", 3, 4, 8),
+    ("tail", 64, 3, "none", 2, 21, 37),
+    ("tail", 32, 3, "none", 1, 16, 16),
+    ("tail", 64, 4, "relu", 2, 5, 50),
+]
+
+
+@pytest.mark.parametrize("kind,cin,cout,act,T,H,W", EDGE_CASES)
+def test_edge_layers_vs_oracle(kind, cin, cout, act, T, H, W):
+    """First layer reading the planar NCHW input, last layer writing planar NCHW with residual (+clamp)."""
+    from bsvd_amd.netspec import pad16
+    rs = np.random.RandomState(cin * 100 + cout + H)
+    st = seeded_state([("l.weight", (cout, cin, 3, 3)), ("l.bias", (cout,))], 9)
+    epi = 0 if kind == "head" else 2
+    net, sp = _one_layer_net(cin, cout, 1, False, act, epi)
+    gex, oex = _gpu_exec(net, st), OracleExecutor(st, double=True)
+    if kind == "head":
+        x = torch.from_numpy(rs.standard_normal((T, cin, H, W)).astype(np.float32))
+        want = oex.conv(sp, x, x_planar=True)
+        got = gex.conv(sp, x.to(_dev()), x_planar=True)
+        assert got.shape == want.shape == (T, H, W, pad16(cout))
+        assert maxabs(got.cpu().numpy(), want.numpy()) < TOL
+        return
+    x = torch.zeros((T, H, W, pad16(cin)))
+    x[..., :cin] = torch.from_numpy(rs.standard_normal((T, H, W, cin)).astype(np.float32))
+    base_planar = torch.from_numpy(rs.standard_normal((T, 4, H, W)).astype(np.float32))
+    base_nhwc = torch.from_numpy(rs.standard_normal((T, H, W, 64)).astype(np.float32))
+    for base, eps, ecs in ((base_planar, 1, H * W), (base_nhwc, 64, 1)):
+        for clamp in (None, (0.0, 1.0)):
+            want = oex.conv(sp, x, extra=base, extra_pstride=eps, extra_cstride=ecs, y_planar=(cout, clamp))
+            got = gex.conv(sp, x.to(_dev()), extra=base.to(_dev()), extra_pstride=eps, extra_cstride=ecs,
+                           y_planar=(cout, clamp))
+            assert got.shape == want.shape == (T, cout, H, W)
+            assert maxabs(got.cpu().numpy(), want.numpy()) < TOL
+
+
 def test_layout_roundtrip_and_clamp():
     net, sp = _one_layer_net(16, 16, 1, False, "none", 0)
     gex = _gpu_exec(net, seeded_state([("l.weight", (16, 16, 3, 3)), ("l.bias", (16,))], 1))

@@ -10,32 +10,39 @@ from oracle_exec import OracleExecutor
 from seeded import seeded_state, state_digest
 from bsvd_amd import checkpoint
 from bsvd_amd.netspec import make_netspec, pad16
-from bsvd_amd.schedule import StreamPipeline, bsvd_clip, Halo
+from bsvd_amd.schedule import StreamPipeline, bsvd_clip, Halo, planar_ok
 
 TOL = 1e-4
 
 
-def run_clip(net, st, x5):
+def run_clip(net, st, x5, planar=True):
     ex = OracleExecutor(st)
+    ex.planar_io = planar
     x = torch.from_numpy(x5).reshape(-1, *x5.shape[2:])
-    xin = ex.to_nhwc(x, net.temp1["inc0"].cin_pad)
-    y = ex.to_nchw(bsvd_clip(ex, net, xin), net.out_ch)
+    pin, pout = planar_ok(ex, net)
+    assert (pin, pout) == (planar, planar)
+    xin = x if pin else ex.to_nhwc(x, net.temp1["inc0"].cin_pad)
+    y = bsvd_clip(ex, net, xin, x_planar=pin, y_planar=(net.out_ch, None) if pout else None)
+    if not pout:
+        y = ex.to_nchw(y, net.out_ch)
     return y.numpy().reshape(x5.shape[0], x5.shape[1], net.out_ch, *x5.shape[3:]), ex
 
 
-def run_stream(net, st, x5, schedule=None):
+def run_stream(net, st, x5, schedule=None, planar=True):
     ex = OracleExecutor(st)
+    ex.planar_io = planar
+    pin, pout = planar_ok(ex, net)
     pipe = StreamPipeline(net)
     x = torch.from_numpy(x5).reshape(-1, *x5.shape[2:])
     T = x.shape[0]
     outs = []
 
     def feed(v):
-        xin = None if v is None else ex.to_nhwc(v, net.temp1["inc0"].cin_pad)
-        y = pipe.feed(ex, xin)
+        xin = None if v is None else (v if pin else ex.to_nhwc(v, net.temp1["inc0"].cin_pad))
+        y = pipe.feed(ex, xin, x_planar=pin, y_planar=(net.out_ch, None) if pout else None)
         if schedule is not None:
             schedule.append([v is None, y is None])
-        return None if y is None else ex.to_nchw(y, net.out_ch)
+        return None if y is None else (y if pout else ex.to_nchw(y, net.out_ch))
 
     for t in range(T):
         outs.append(feed(x[t:t + 1]))
@@ -62,6 +69,10 @@ def test_small_net_clip_and_stream(T):
     net = make_netspec([32, 64, 128], 32, 4, 3, "relu6", 32)
     y, ex = run_clip(net, st, g["x"])
     assert ex.launches == 32
+    assert maxabs(y, g["out"]) < TOL
+    y, ex = run_clip(net, st, g["x"], planar=False)          # generic entry/exit (layout kernels) path
+    assert maxabs(y, g["out"]) < TOL
+    y, _ = run_stream(net, st, g["x"], planar=False)
     assert maxabs(y, g["out"]) < TOL
     sched = []
     y, pipe = run_stream(net, st, g["x"], sched)
