@@ -1,0 +1,128 @@
+"""Callers of the hot path, call-compatible with the reference's inference harness:
+
+* ``temp_denoise`` / ``denoise_seq``  <->  /root/reference/Experimental_root/models/validation_seq_infer.py:10-100
+* ``DenoisingModel`` (test path only) <->  /root/reference/Experimental_root/models/denoising_model.py:16-190
+  (``feed_data`` :91, ``padding_input`` :133, ``crop_output`` :161, ``test`` :170, ``get_current_visuals`` :369)
+
+Semantics reproduced (pinned by tests/golden/g8_pad_crop_clamp.npz): H and W are padded on the right/bottom to
+multiples of 4 with reflection; the noise map is rebuilt as a constant from its first element; with
+``temp_psz == -1`` the whole clip goes through the network in ONE call; outputs are clamped to [0, 1]; the pad is
+cropped again.  For ``temp_psz > 0`` the clip is cut into independent segments with a mirrored tail, as the
+reference does for a ``BSVD`` network (whose buffers are reset per call).  Training, losses, EMA, logging and image
+dumping of the reference class are out of scope.
+"""
+import torch
+import torch.nn.functional as F
+
+from .registry import MODEL_REGISTRY, build_network
+
+
+def temp_denoise(model, noisyframe, sigma_noise, device=None):
+    """noisyframe [F,C,H,W] in [0,1]; sigma_noise [F,1,H,W] constant map or None -> clamped [F,C_out,H,W]."""
+    n, _, h, w = noisyframe.shape
+    clip = noisyframe[None]
+    if sigma_noise is not None:
+        first = sigma_noise[0, 0, 0, 0]
+        if abs(float(sigma_noise.float().mean()) - float(first)) >= 1e-5:
+            raise AssertionError("the noise map must be constant (validation_seq_infer.py:19)")
+        sigma = torch.full((1, n, 1, h, w), float(first), dtype=noisyframe.dtype, device=noisyframe.device)
+        out = model(clip, noise_map=sigma)[0]
+    else:
+        out = model(clip)[0]
+    out = torch.clamp(out, 0.0, 1.0)
+    if out.is_cuda:
+        torch.cuda.synchronize(out.device)
+    return out if device is None else out.to(device)
+
+
+def denoise_seq(seq, noise_map, temp_psz, model_temporal, future_buffer_len=0):
+    """seq [T,C,H,W] -> denoised [T,C,H,W] on seq's device (float32)."""
+    dev = next(model_temporal.parameters()).device
+    T, C, H, W = seq.shape
+    if temp_psz == -1:
+        temp_psz = T                                   # BSVD: the whole video in a single forward
+    out = torch.empty((T, C, H, W), dtype=torch.float32, device=seq.device)
+    nseg = T // temp_psz
+    for i in range(nseg):
+        a, b = i * temp_psz, (i + 1) * temp_psz
+        b_in = b + future_buffer_len if b + future_buffer_len <= T else b
+        res = temp_denoise(model_temporal, seq[a:b_in].to(dev), noise_map, seq.device)
+        out[a:b] = res[:temp_psz]
+    rest = T - nseg * temp_psz
+    if rest > 0:
+        # mirror-extend the tail to a full segment, keep the first `rest` outputs (validation_seq_infer.py:75-90)
+        tail = torch.cat((seq[nseg * temp_psz:], torch.flip(seq[-(temp_psz - rest) - 1:-1], dims=[0])))
+        res = temp_denoise(model_temporal, tail.to(dev), noise_map, seq.device)
+        out[nseg * temp_psz:] = res[:rest]
+    return out
+
+
+def pad_to_multiple_of_4(frames):
+    """[F,C,H,W] -> (padded, padding_list) with padding_list = [0, pad_w, 0, pad_h, 0, 0] (right/bottom reflect)."""
+    h, w = frames.shape[-2:]
+    pad_h = (4 - h % 4) % 4
+    pad_w = (4 - w % 4) % 4
+    padded = F.pad(frames, (0, pad_w, 0, pad_h), mode="reflect") if (pad_h or pad_w) else frames
+    return padded, [0, pad_w, 0, pad_h, 0, 0]
+
+
+def crop_padding(output, padding_list):
+    """output [1,F,C,H,W]; inverse of pad_to_multiple_of_4."""
+    pw1, pw2, ph1, ph2, t1, t2 = padding_list
+    _, f, _, h, w = output.shape
+    return output[:, t1:f - t2, :, ph1:h - ph2, pw1:w - pw2]
+
+
+@MODEL_REGISTRY.register()
+class DenoisingModel:
+    """Inference half of the reference's DenoisingModel: opt dict in, ``feed_data`` / ``test`` /
+    ``get_current_visuals`` out.  ``opt['network_g']`` is splatted into the arch constructor exactly like
+    basicsr.archs.build_network does; ``opt['val']['temp_psz']`` (-1 for BSVD) and ``future_buffer_len`` are
+    honoured; ``opt['num_gpu'] == 0`` is rejected (the engine is GPU-only)."""
+
+    def __init__(self, opt):
+        self.opt = opt
+        self.is_train = bool(opt.get("is_train", False))
+        if self.is_train:
+            raise NotImplementedError("bsvd_amd implements the inference path only (training is out of scope)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("DenoisingModel needs a HIP device")
+        self.device = torch.device("cuda")
+        self.net_g = build_network(opt["network_g"]).to(self.device)
+        path = (opt.get("path") or {}).get("pretrain_network_g")
+        if path:
+            self.net_g.load(path)
+        self.lq = self.gt = self.noise_map = self.output = None
+
+    def feed_data(self, data):
+        self.lq = data["lq"].to(self.device)
+        self.noise_map = data["noise_map"].to(self.device) if "noise_map" in data else None
+        if "gt" in data:
+            self.gt = data["gt"].to(self.device)
+
+    def padding_input(self, frames):
+        return pad_to_multiple_of_4(frames)
+
+    def crop_output(self, padding_list):
+        self.output = crop_padding(self.output, padding_list)
+
+    def test(self):
+        """lq: [F,C,H,W] (or [1,F,C,H,W]) in [0,1]; result in self.output as [1,F,C,H,W]."""
+        lq = self.lq[0] if self.lq.dim() == 5 else self.lq
+        nm = None
+        if self.noise_map is not None:
+            nm = self.noise_map[0] if self.noise_map.dim() == 5 else self.noise_map
+        self.net_g.eval()
+        val = self.opt.get("val") or {}
+        with torch.no_grad():
+            padded, plist = self.padding_input(lq)
+            pnm = self.padding_input(nm)[0] if nm is not None else None
+            self.output = denoise_seq(padded, pnm, val.get("temp_psz", -1), self.net_g,
+                                      future_buffer_len=val.get("future_buffer_len", 0))[None]
+            self.crop_output(plist)
+
+    def get_current_visuals(self):
+        out = {"lq": self.lq.detach().cpu(), "result": self.output.detach().cpu()}
+        if self.gt is not None:
+            out["gt"] = self.gt.detach().cpu()
+        return out

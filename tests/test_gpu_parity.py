@@ -269,6 +269,34 @@ def test_full_resolution_two_frames_vs_oracle():
     assert torch.equal(m(x.to(_dev())).cpu(), y)
 
 
+def test_denoising_model_pad_clamp_crop_end_to_end():
+    """DenoisingModel.test() protocol (denoising_model.py:170-190) on a 30x50 clip (not a multiple of 4):
+    reflect pad -> whole clip in one call with a constant noise map -> clamp -> crop, vs the CPU oracle."""
+    import torch.nn.functional as F
+    import bsvd_amd
+    from oracle import bsvd_oracle as O
+    st = seeded_state(bsvd_keys([32, 64, 128], 32, 4, 3, 32), 21)
+    opt = {"is_train": False, "num_gpu": 1, "val": {"temp_psz": -1},
+           "network_g": {"type": "BSVD" if "BSVD" in bsvd_amd.ARCH_REGISTRY else "BSVD_MI355X", "chns": [32, 64, 128],
+                         "mid_ch": 32, "shift_input": False, "in_ch": 4, "out_ch": 3, "norm": "none", "act": "relu6",
+                         "interm_ch": 32, "blind": False, "pretrain_ckpt": None}}
+    model = bsvd_amd.MODEL_REGISTRY.get("DenoisingModel")(opt)
+    model.net_g.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
+    rs = np.random.RandomState(22)
+    gt = torch.from_numpy(rs.uniform(0, 1, (6, 3, 30, 50)).astype(np.float32))
+    lq = gt + torch.from_numpy(rs.standard_normal(gt.shape).astype(np.float32)) * (30 / 255.0)
+    nm = torch.full((6, 1, 30, 50), 30 / 255.0)
+    model.feed_data({"lq": lq, "gt": gt, "noise_map": nm})
+    model.test()
+    got = model.get_current_visuals()["result"]
+    assert got.shape == (1, 6, 3, 30, 50)
+    pl = F.pad(lq, (0, 2, 0, 2), mode="reflect")
+    pn = torch.full((1, 6, 1, 32, 52), 30 / 255.0)
+    cfg = O.default_cfg(chns=[32, 64, 128], mid_ch=32, interm_ch=32)
+    want = O.bsvd_clip(pl[None], O.to_torch_state(st), cfg, noise_map=pn).clamp(0, 1)[..., :30, :50]
+    assert maxabs(got.numpy(), want.numpy()) < TOL
+
+
 def test_rejects_bad_arguments():
     from bsvd_amd import _lib
     import ctypes
