@@ -217,6 +217,13 @@ def main():
         dom = max(agg, key=lambda k: agg[k]["ms"])
         conv_ms = sum(v["ms"] for v in agg.values())
         ach = agg[dom]["flop"] / (agg[dom]["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/make_traffic.py)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/traffic.json (%s; %s)" % (tj["source"], tj["formula"])
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "denoised frames/sec @540x960 sigma=30 (bsvd_c64 streaming bidirectional-buffer forward)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -230,7 +237,8 @@ def main():
             "path_tflops": fps * flop_per_frame / 1e12,
             "path_frac_of_f32_mfma_peak": fps * flop_per_frame / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC, separate passes)", "traffic_source": traffic_src,
                          "avg_launch_ms": agg[dom]["ms"] / agg[dom]["launches"], "launches": agg[dom]["launches"],
                          "all_conv_kernels": {k: {"ms_per_step": v["ms"] / args.steps,
                                                   "tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12,

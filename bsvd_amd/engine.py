@@ -92,13 +92,22 @@ class HipExecutor:
         self.launches += 1
         return out
 
+    def out_shape(self, sp, x):
+        """Shape of the NHWC tensor layer ``sp`` produces from NHWC input ``x``."""
+        T, H, W, _ = x.shape
+        Ho, Wo = (H - 1) // sp.stride + 1, (W - 1) // sp.stride + 1
+        if sp.epilogue == EPI_PS_ADD:
+            return (T, 2 * Ho, 2 * Wo, sp.cout_pad // 4)
+        return (T, Ho, Wo, sp.cout_pad)
+
     # -- the fused layer -------------------------------------------------------------------------
     planar_io = True      # the edge kernels read planar NCHW input / write planar NCHW output directly
 
     def conv(self, sp, x, halo_prev=None, halo_next=None, extra=None, extra_pstride=0, extra_cstride=1,
-             x_planar=False, y_planar=None):
+             x_planar=False, y_planar=None, out=None):
         """x_planar: x is the caller's planar [T,C,H,W] tensor (first layer).  y_planar=(channels, clamp|None):
-        write the planar [T,channels,H,W] result directly (last layer)."""
+        write the planar [T,channels,H,W] result directly (last layer).  out: optional preallocated (contiguous,
+        e.g. a frame range of a larger tensor) destination instead of a fresh allocation."""
         a = _lib.BsvdConvArgs()
         if not x.is_contiguous():
             raise ValueError("%s: input must be contiguous" % sp.key)
@@ -126,6 +135,10 @@ class HipExecutor:
             y = torch.empty((T, 2 * Ho, 2 * Wo, sp.cout_pad // 4), dtype=torch.float32, device=x.device)
         else:
             y = torch.empty((T, Ho, Wo, sp.cout_pad), dtype=torch.float32, device=x.device)
+        if out is not None:
+            if tuple(out.shape) != tuple(y.shape) or not out.is_contiguous() or out.dtype != y.dtype:
+                raise ValueError("%s: out has shape %s, expected contiguous %s" % (sp.key, tuple(out.shape), tuple(y.shape)))
+            y = out
         wp, bp = self.packed.tensors[sp.key]
         a.x = x.data_ptr()
         if sp.tsm:

@@ -42,10 +42,23 @@ def denblock_clip(ex, S, x, halo_fn=None, x_planar=False, y_planar=None):
     is a frame-window shard.  y_planar=(channels, clamp) makes the last layer write planar NCHW."""
 
     def tsm(name, v):
-        hp = hn = None
-        if halo_fn is not None:
-            hp, hn = halo_fn(S[name], v)
-        return ex.conv(S[name], v, halo_prev=hp, halo_next=hn)
+        sp = S[name]
+        if halo_fn is None:
+            return ex.conv(sp, v)
+        T, C = v.shape[0], v.shape[-1]
+        if hasattr(halo_fn, "start") and T >= 3:
+            # overlap: the exchange of the two boundary slices runs (on the communication stream) while the
+            # interior frames -- whose temporal neighbours are all local -- are convolved; the two boundary
+            # frames follow once the neighbours' slices have arrived.
+            pending = halo_fn.start(sp, v)
+            y = v.new_empty(ex.out_shape(sp, v))
+            ex.conv(sp, v[1:-1], halo_prev=Halo(v[0], C, sp.fold), halo_next=Halo(v[-1], C, 0), out=y[1:-1])
+            hp, hn = pending.finish()
+            ex.conv(sp, v[0:1], halo_prev=hp, halo_next=Halo(v[1], C, 0), out=y[0:1])
+            ex.conv(sp, v[-1:], halo_prev=Halo(v[-2], C, sp.fold), halo_next=hn, out=y[-1:])
+            return y
+        hp, hn = halo_fn(sp, v)
+        return ex.conv(sp, v, halo_prev=hp, halo_next=hn)
 
     a = ex.conv(S["inc0"], x, x_planar=True) if x_planar else ex.conv(S["inc0"], x)
     x0 = ex.conv(S["inc3"], a)

@@ -15,7 +15,7 @@ from bsvd_amd.netspec import EPI_PS_ADD, EPI_RESID
 def _slice_from_halo(halo, hw, n):
     """[HW, n] view of a Halo(t, pstride, coff)."""
     flat = halo.t.reshape(-1)
-    return torch.as_strided(flat, (hw, n), (halo.pstride, 1), storage_offset=halo.coff)
+    return torch.as_strided(flat, (hw, n), (halo.pstride, 1), storage_offset=flat.storage_offset() + halo.coff)
 
 
 class OracleExecutor:
@@ -37,13 +37,23 @@ class OracleExecutor:
             y = y.clamp(clamp[0], clamp[1])
         return y
 
+    def out_shape(self, sp, x):
+        T, H, W, _ = x.shape
+        Ho, Wo = (H - 1) // sp.stride + 1, (W - 1) // sp.stride + 1
+        if sp.epilogue == EPI_PS_ADD:
+            return (T, 2 * Ho, 2 * Wo, sp.cout_pad // 4)
+        return (T, Ho, Wo, sp.cout_pad)
+
     def halo_pack(self, frame, c0, n):
         return frame[..., c0:c0 + n].contiguous()
 
     planar_io = True
 
     def conv(self, sp, x, halo_prev=None, halo_next=None, extra=None, extra_pstride=0, extra_cstride=1,
-             x_planar=False, y_planar=None):
+             x_planar=False, y_planar=None, out=None):
+        if out is not None:
+            out.copy_(self.conv(sp, x, halo_prev, halo_next, extra, extra_pstride, extra_cstride, x_planar, y_planar))
+            return out
         self.launches += 1
         self.log.append(sp.key)
         if x_planar:
@@ -83,15 +93,18 @@ class OracleExecutor:
             out = torch.zeros((T, 2 * Ho, 2 * Wo, sp.cout_pad // 4), dtype=torch.float32)
             out[..., :cq] = y.permute(0, 2, 3, 1)
             if extra is not None:
-                e = torch.as_strided(extra.reshape(-1), (T, 4 * Ho * Wo, cq),
-                                     (extra[0].numel(), extra_pstride, extra_cstride))
+                ef = extra.reshape(-1)
+                e = torch.as_strided(ef, (T, 4 * Ho * Wo, cq), (extra[0].numel(), extra_pstride, extra_cstride),
+                                     storage_offset=ef.storage_offset())
                 out[..., :cq] += e.reshape(T, 2 * Ho, 2 * Wo, cq)
             return out
         out = torch.zeros((T, Ho, Wo, sp.cout_pad), dtype=torch.float32)
         out[..., :sp.cout] = y.permute(0, 2, 3, 1)
         if sp.epilogue == EPI_RESID:
             k = min(3, sp.cout)
-            e = torch.as_strided(extra.reshape(-1), (T, Ho * Wo, k), (extra[0].numel(), extra_pstride, extra_cstride))
+            ef = extra.reshape(-1)
+            e = torch.as_strided(ef, (T, Ho * Wo, k), (extra[0].numel(), extra_pstride, extra_cstride),
+                                 storage_offset=ef.storage_offset())
             out[..., :k] = e.reshape(T, Ho, Wo, k) - out[..., :k]
         if y_planar is not None:
             yc, clamp = y_planar

@@ -236,16 +236,27 @@ def test_sharded_equals_unsharded_bitwise():
         torch.cuda.set_device(0)
         e = _gpu_exec(net, st)
 
-        def halo_fn(sp, v):
-            fold = sp.fold
-            boxes[(r, sp.key)] = (e.halo_pack(v[0], 0, fold), e.halo_pack(v[-1], fold, fold))
-            torch.cuda.synchronize()
-            barrier.wait()
-            other = boxes[(1 - r, sp.key)]
-            barrier.wait()
-            return (None, Halo(other[0], fold, 0)) if r == 0 else (Halo(other[1], fold, 0), None)
+        class ThreadHalo:
+            """Two lock-stepped 'ranks' on one GPU.  start()/finish() exercises the overlapped schedule
+            (interior frames first, writes into frame ranges of one output tensor) for shards of >= 3 frames."""
 
-        results[r] = e.to_nchw(bsvd_clip(e, net, e.to_nhwc(frames, 16), halo_fn), 3)
+            def start(self, sp, v):
+                fold = sp.fold
+                boxes[(r, sp.key)] = (e.halo_pack(v[0], 0, fold), e.halo_pack(v[-1], fold, fold))
+
+                class P:
+                    def finish(self_p):
+                        torch.cuda.synchronize()
+                        barrier.wait()
+                        other = boxes[(1 - r, sp.key)]
+                        barrier.wait()
+                        return (None, Halo(other[0], fold, 0)) if r == 0 else (Halo(other[1], fold, 0), None)
+                return P()
+
+            def __call__(self, sp, v):
+                return self.start(sp, v).finish()
+
+        results[r] = e.to_nchw(bsvd_clip(e, net, e.to_nhwc(frames, 16), ThreadHalo()), 3)
         torch.cuda.synchronize()
 
     th = [threading.Thread(target=rank, args=(0, x[:2])), threading.Thread(target=rank, args=(1, x[2:]))]

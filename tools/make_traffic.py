@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch from rocprofv3 PMC passes (tools/pmc_run.sh): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
+FETCH_SIZE/WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
+reads, hence the factor 2 (/opt/skills/guides/MI355X_MICROARCH.md, HBM section).  WRITE_SIZE calibrates 1:1 on this
+workload: the conv kernels' measured 597 MB/launch equals their algorithmic output bytes exactly.
+usage: make_traffic.py <pmc dir> <out json>"""
+import collections, csv, glob, json, os, sys
+d, out = sys.argv[1], sys.argv[2]
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+disp = collections.defaultdict(lambda: collections.defaultdict(set))
+for f in sorted(glob.glob(os.path.join(d, "pass*", "*counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE") or "bsvd::" not in r["Kernel_Name"]:
+            continue
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("bsvd::", "").replace("ConvCfg", "").replace(" ", "")
+        k = k.replace("<<", "<").replace(">,true>", ">").replace(">,false>", ">[generic]")   # bench.py's variant names
+        k = "head_kernel" if k.startswith("head_kernel") else ("tail_kernel" if k.startswith("tail_kernel") else k)
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+res = {}
+for k, v in agg.items():
+    nf, nw = len(disp[k]["FETCH_SIZE"]), len(disp[k]["WRITE_SIZE"])
+    fetch = v["FETCH_SIZE"] / max(nf, 1) * 1024.0
+    write = v["WRITE_SIZE"] / max(nw, 1) * 1024.0
+    res[k] = {"launches_sampled": nf, "fetch_bytes_raw": fetch, "write_bytes": write, "hbm_bytes_per_launch": 2 * fetch + write}
+json.dump({"source": os.path.basename(d.rstrip("/")), "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch",
+           "kernels": res}, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))
