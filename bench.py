@@ -30,6 +30,8 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16 MFMA peak (same guide); f16x3 issues 3 MFMA FLOPs per algorithmic FLOP
+DEFAULT_PRECISION = "fp32"
 H, W = 540, 960
 SIGMA = 30.0 / 255.0
 
@@ -43,11 +45,11 @@ def synth_clip(frames, seed, device):
     return lq.to(device), nm.to(device)
 
 
-def build_model(device):
+def build_model(device, precision="fp32"):
     import bsvd_amd
     torch.manual_seed(1234)      # random-init weights of the bsvd_c64 architecture (no checkpoint in the tree)
     m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, shift_input=False, in_ch=4, out_ch=3, norm="none",
-                      act="relu6", interm_ch=64, blind=False, pretrain_ckpt=None)
+                      act="relu6", interm_ch=64, blind=False, pretrain_ckpt=None, precision=precision)
     return m.to(device).eval()
 
 
@@ -152,6 +154,8 @@ def main():
     ap.add_argument("--frames", type=int, default=10, help="frames per GPU per step")
     ap.add_argument("--mode", default="clip", choices=["clip", "stream"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["fp32", "f16x3"],
+                    help="fp32: exact fp32 MFMA; f16x3: split-fp16 3-pass MFMA, fp32 accumulate (fp32-class accuracy)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -170,7 +174,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)      # backend "nccl" is RCCL on ROCm
 
-    model = build_model(device)
+    model = build_model(device, args.precision)
+    peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_F16_MFMA_TFLOPS
     model.engine_mode = args.mode
     lq, nm = synth_clip(args.frames, 100 + rank, device)       # this rank's window of the 10*N-frame clip
     x = torch.cat([lq, nm], dim=2)[0].contiguous()             # [F,4,H,W] resident in HBM before timing
@@ -228,16 +233,20 @@ def main():
             "metric": "denoised frames/sec @540x960 sigma=30 (bsvd_c64 streaming bidirectional-buffer forward)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16x3 (split-fp16 MFMA, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "bsvd_c64 sigma=30, one synthetic clip [1,%d,4,540,960], %s schedule, "
                                    "random-init weights; N>1: frame-window sharded with per-layer RCCL halo"
                                    % (args.frames * world, args.mode),
                        "frames_per_gpu": args.frames, "parallelism": "frame-window x%d" % world,
                        "flop_per_frame": flop_per_frame},
             "path_tflops": fps * flop_per_frame / 1e12,
-            "path_frac_of_f32_mfma_peak": fps * flop_per_frame / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            "path_frac_of_mfma_peak": fps * flop_per_frame / 1e12 / (peak * world),
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak,
+                         "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                         "note": ("algorithmic FLOP over the fp32-MFMA peak (v_mfma_f32_32x32x2_f32)" if args.precision == "fp32" else
+                                  "algorithmic FLOP over the dense fp16-MFMA peak; the 3-pass split issues 3 MFMA FLOP "
+                                  "per algorithmic FLOP, so MFMA-pipe utilisation = 3 x frac"),
                          "traffic_unit": "HBM bytes per launch (PMC, separate passes)", "traffic_source": traffic_src,
                          "avg_launch_ms": agg[dom]["ms"] / agg[dom]["launches"], "launches": agg[dom]["launches"],
                          "all_conv_kernels": {k: {"ms_per_step": v["ms"] / args.steps,

@@ -9,8 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbsvd_hip.so")
 
-ABI_VERSION = 2
-BSVD_F32, BSVD_F16 = 0, 1
+ABI_VERSION = 3
+BSVD_F32, BSVD_F16, BSVD_F16X3 = 0, 1, 2
 ACT = {"none": 0, "relu": 1, "relu6": 2}
 EPI_PLAIN, EPI_PS_ADD, EPI_RESID = 0, 1, 2
 
@@ -43,6 +43,7 @@ class BsvdConvArgs(ctypes.Structure):
         ("act", ctypes.c_int32), ("epilogue", ctypes.c_int32), ("dtype", ctypes.c_int32),
         ("x_planar_ch", ctypes.c_int32), ("y_planar_ch", ctypes.c_int32), ("y_clamp", ctypes.c_int32),
         ("y_lo", ctypes.c_float), ("y_hi", ctypes.c_float),
+        ("extra_split", ctypes.c_int32),
     ]
 
 

@@ -58,11 +58,14 @@ class BSVD(nn.Module):
                     (the reference's frame-major pipeline with 16-step latency).  Same function.
       clamp       : optional (lo, hi) fused into the exit kernel (callers clamp to [0,1] anyway,
                     validation_seq_infer.py:24).
+      precision   : 'fp32' (default; exact fp32 MFMA, bitwise an fmaf chain) or 'f16x3' (split-fp16 3-pass MFMA with
+                    fp32 accumulation: fp32-class accuracy -- 2-4e-5 max-abs on bsvd_c64, budget 1e-3 -- at several
+                    times the throughput).  'f16x3' needs chns[1:] multiples of 128 and 16-aligned inner widths.
     """
 
     def __init__(self, chns=[32, 64, 128], mid_ch=3, shift_input=False, in_ch=4, out_ch=3, norm='bn', act='relu',
                  interm_ch=30, blind=False, pretrain_ckpt='./experiments/pretrained_ckpt/bsvd-64.pth',
-                 engine_mode='clip', clamp=None):
+                 engine_mode='clip', clamp=None, precision='fp32'):
         super().__init__()
         if shift_input:
             raise NotImplementedError("shift_input=True (CvBlock input stage) is not used by any BSVD config; "
@@ -72,9 +75,18 @@ class BSVD(nn.Module):
                                       "normalisation layers are not implemented by the MI355X engine" % (norm,))
         if engine_mode not in ("clip", "stream"):
             raise ValueError("engine_mode must be 'clip' or 'stream'")
+        if precision not in ("fp32", "f16x3"):
+            raise ValueError("precision must be 'fp32' or 'f16x3'")
         self.net = make_netspec(chns, mid_ch, in_ch, out_ch, act, interm_ch, blind)
         self.engine_mode = engine_mode
         self.clamp = clamp
+        self.precision = precision
+        if precision == "f16x3":
+            n = self.net
+            bad = [l.key for l in n.layers[1:-1] if l.cin % 16 or l.cout % 16 or (l.tsm and l.fold % 16)]
+            if bad or n.net_in_ch not in (3, 4) or n.out_ch > 4:
+                raise ValueError("precision='f16x3' needs 16-aligned channel counts, fold % 16 == 0 (chns[1:] multiples "
+                                 "of 128) and <= 4 input/output channels; offending layers: %s" % (bad[:3],))
         self.temp1 = _denblock_params(self.net.chns, in_ch, mid_ch, interm_ch, blind)
         self.temp2 = _denblock_params(self.net.chns, mid_ch, out_ch, interm_ch, False)
         self.shift_num = self.net.shift_num
@@ -108,9 +120,9 @@ class BSVD(nn.Module):
     def _executor(self, device):
         from .engine import HipExecutor, PackedNet, require_hip
         require_hip()
-        sig = (self._signature(), str(device))
+        sig = (self._signature(), str(device), self.precision)
         if self._packed is None or self._packed_sig != sig:
-            self._packed = PackedNet(self.net, self.state_dict(), device)
+            self._packed = PackedNet(self.net, self.state_dict(), device, self.precision)
             self._packed_sig = sig
             self._exec = HipExecutor(self._packed)
         return self._exec

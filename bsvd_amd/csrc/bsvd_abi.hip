@@ -58,6 +58,50 @@ __global__ void pack_weights_kernel(const float *__restrict__ w, const float *__
     }
 }
 
+// split16 weights: [Cin_pad/16][9][part: hi, lo][h = 2][Cout_pad][8 fp16]; element (h, j) is input channel 8h + j of the
+// chunk -- the k-slot lane (n, h) of v_mfma_f32_32x32x16_f16 feeds.  Same byte size as the fp32 pack.
+__global__ void pack_weights_split_kernel(const float *__restrict__ w, const float *__restrict__ bias, int Cin, int Cout,
+                                          int Cin_pad, int Cout_pad, int ps, _Float16 *__restrict__ wp,
+                                          float *__restrict__ bp)
+{
+    const int64_t total = (int64_t)Cin_pad * 9 * Cout_pad * 2;
+    const int Cq_pad = Cout_pad >> 2, Cq = Cout >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int j = t & 7; t >>= 3;
+        const int np = (int)(t % Cout_pad); t /= Cout_pad;
+        const int h = t & 1; t >>= 1;
+        const int part = t & 1; t >>= 1;
+        const int tap = (int)(t % 9);
+        const int cb = (int)(t / 9);
+        const int c = cb * 16 + h * 8 + j;
+        int n = np;
+        bool ok = c < Cin;
+        if (ps) {
+            const int sub = np / Cq_pad, ch = np - sub * Cq_pad;
+            ok = ok && ch < Cq;
+            n = 4 * ch + sub;
+        } else {
+            ok = ok && np < Cout;
+        }
+        const float v = ok ? w[((int64_t)n * Cin + c) * 9 + tap] : 0.f;
+        const _Float16 hi = (_Float16)v;
+        wp[i] = part ? (_Float16)(v - (float)hi) : hi;
+        if (bp && i < Cout_pad) {
+            int nb = (int)i;
+            bool okb;
+            if (ps) {
+                const int sub = nb / Cq_pad, ch = nb - sub * Cq_pad;
+                okb = ch < Cq;
+                nb = 4 * ch + sub;
+            } else {
+                okb = nb < Cout;
+            }
+            bp[i] = (okb && bias) ? bias[nb] : 0.f;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // clip entry / exit
 __global__ void nchw_to_nhwc_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int HW, int Cpad,
@@ -123,7 +167,7 @@ int64_t bsvd_packed_weight_elems(int32_t Cin_pad, int32_t Cout_pad) { return (in
 int bsvd_conv3x3(const BsvdConvArgs *a, void *stream)
 {
     if (!a) { set_error("bsvd_conv3x3: args is NULL"); return -1; }
-    if (a->dtype != BSVD_F32) { set_error("bsvd_conv3x3: dtype %d not supported (BSVD_F32 only)", a->dtype); return -2; }
+    if (a->dtype != BSVD_F32 && a->dtype != BSVD_F16X3) { set_error("bsvd_conv3x3: dtype %d not supported (BSVD_F32, BSVD_F16X3)", a->dtype); return -2; }
     if (!a->x || !a->y || !a->w_packed) { set_error("bsvd_conv3x3: x, y and w_packed must be non-NULL"); return -3; }
     if (a->frames <= 0 || a->H <= 0 || a->W <= 0) { set_error("bsvd_conv3x3: bad clip size %d x %d x %d", a->frames, a->H, a->W); return -4; }
     if (a->Cin <= 0 || (a->Cin & 15) || a->Cout <= 0 || (a->Cout & 15)) {
@@ -166,6 +210,8 @@ int bsvd_conv3x3(const BsvdConvArgs *a, void *stream)
         vec = vec && (a->halo_next_pstride & 3) == 0 && (a->halo_next_coff & 3) == 0 && (((uintptr_t)a->halo_next) & 15) == 0;
     p.vec_ok = vec ? 1 : 0;
     p.ablate = 0;
+    p.prec = a->dtype == BSVD_F16X3 ? 1 : 0;
+    p.extra_split = a->extra_split;
 #ifdef BSVD_ABLATE
     if (const char *e = getenv("BSVD_ABLATE")) p.ablate = atoi(e);
 #endif
@@ -182,13 +228,13 @@ int bsvd_conv3x3(const BsvdConvArgs *a, void *stream)
         if (a->epilogue == BSVD_EPI_RESID && a->resid_ch > a->y_planar_ch) { set_error("bsvd_conv3x3: resid_ch > y_planar_ch"); return -16; }
         return launch_tail_f32(p, a->y_planar_ch, a->y_clamp, a->y_lo, a->y_hi, (hipStream_t)stream);
     }
-    return launch_conv3x3_f32(p, a->stride, (hipStream_t)stream);
+    return launch_conv3x3(p, a->stride, (hipStream_t)stream);
 }
 
 int bsvd_pack_weights(const float *w, const float *bias, int32_t Cin, int32_t Cout, int32_t Cin_pad, int32_t Cout_pad,
                       int32_t pixel_shuffle, int32_t dtype, void *wp, void *bp, void *stream)
 {
-    if (dtype != BSVD_F32) { set_error("bsvd_pack_weights: dtype %d not supported", dtype); return -2; }
+    if (dtype != BSVD_F32 && dtype != BSVD_F16X3) { set_error("bsvd_pack_weights: dtype %d not supported", dtype); return -2; }
     if (!w || !wp) { set_error("bsvd_pack_weights: NULL weight pointer"); return -3; }
     if (Cin <= 0 || Cout <= 0 || Cin_pad < Cin || Cout_pad < Cout || (Cin_pad & 15) || (Cout_pad & 15)) {
         set_error("bsvd_pack_weights: bad sizes Cin %d->%d Cout %d->%d", Cin, Cin_pad, Cout, Cout_pad); return -5;
@@ -197,6 +243,11 @@ int bsvd_pack_weights(const float *w, const float *bias, int32_t Cin, int32_t Co
         set_error("bsvd_pack_weights: pixel_shuffle needs Cout %% 4 == 0 and Cout_pad %% 64 == 0"); return -10;
     }
     const int64_t total = bsvd_packed_weight_elems(Cin_pad, Cout_pad);
+    if (dtype == BSVD_F16X3) {
+        hipLaunchKernelGGL(pack_weights_split_kernel, dim3(grid_for(2 * total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                           bias, Cin, Cout, Cin_pad, Cout_pad, pixel_shuffle ? 1 : 0, (_Float16 *)wp, (float *)bp);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, w, bias, Cin,
                        Cout, Cin_pad, Cout_pad, pixel_shuffle ? 1 : 0, (float *)wp, (float *)bp);
     return (int)hipGetLastError();

@@ -23,12 +23,14 @@ struct ConvParams {
     int32_t ntx, nty, nct;   // tiles in x, y and output-channel tiles
     int32_t vec_ok;          // 1: every 4-channel group of the gather comes from one source, 16-B aligned
     int32_t ablate;          // only read by -DBSVD_ABLATE timing builds (tools/), always 0 in the product
+    int32_t prec;            // 0 = exact fp32, 1 = split16 (BSVD_F16X3)
+    int32_t extra_split;     // tail kernel: the residual base is a split16 NHWC tensor
 };
 
 void set_error(const char *fmt, ...);
 
-// conv3x3_f32_mfma.hip
-int launch_conv3x3_f32(const ConvParams &p, int stride, hipStream_t stream);
+// conv3x3_mfma.hip
+int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream);
 
 // conv3x3_edge_f32.hip
 int launch_head_f32(const ConvParams &p, int cin_real, hipStream_t stream);

@@ -7,7 +7,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
 mkdir -p "$HERE/obj"
 pids=()
-for src in conv3x3_f32_mfma conv3x3_edge_f32 bsvd_abi; do
+for src in conv3x3_mfma conv3x3_edge_f32 bsvd_abi; do
   if [ ! -f "$HERE/obj/$src.o" ] || [ "$HERE/$src.hip" -nt "$HERE/obj/$src.o" ] || \
      [ "$HERE/bsvd_internal.h" -nt "$HERE/obj/$src.o" ] || [ "$ROOT/include/bsvd_hip.h" -nt "$HERE/obj/$src.o" ]; then
     $HIPCC $FLAGS ${EXTRA_HIPCC_FLAGS} -c "$HERE/$src.hip" -o "$HERE/obj/$src.o" &

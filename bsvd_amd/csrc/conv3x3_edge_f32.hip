@@ -19,6 +19,7 @@
 namespace bsvd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // Weights/bias are read-only for the whole launch and indexed wave-uniformly: reading them through the constant
 // address space lets the compiler use scalar loads (SGPR operands) even with stores in the same loop.
 typedef const __attribute__((address_space(4))) float *cfloat_p;
@@ -73,7 +74,20 @@ __global__ __launch_bounds__(256) void head_kernel(const ConvParams p)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[j] = fmaf(in[tap][c], wt[j * 4 + c], acc[j]);
         }
-        if (live) {
+        if (live && p.prec == 1) {          // split16 output: [hi x16 | lo x16] in the chunk's 64 bytes
+            f16x8 hi[2], lo[2];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float v = edge_act(acc[j], p.act);
+                const _Float16 h = (_Float16)v;
+                hi[j >> 3][j & 7] = h;
+                lo[j >> 3][j & 7] = (_Float16)(v - (float)h);
+            }
+            *reinterpret_cast<f32x4 *>(yout + nb) = __builtin_bit_cast(f32x4, hi[0]);
+            *reinterpret_cast<f32x4 *>(yout + nb + 4) = __builtin_bit_cast(f32x4, hi[1]);
+            *reinterpret_cast<f32x4 *>(yout + nb + 8) = __builtin_bit_cast(f32x4, lo[0]);
+            *reinterpret_cast<f32x4 *>(yout + nb + 12) = __builtin_bit_cast(f32x4, lo[1]);
+        } else if (live) {
 #pragma unroll
             for (int j4 = 0; j4 < 4; ++j4) {
                 f32x4 v;
@@ -150,9 +164,23 @@ __global__ __launch_bounds__(256) void tail_kernel(const ConvParams p, int y_pla
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
             const float *ap = cur + ((py + ky) * C::PWD + (px + kx)) * C::PS;
+            f32x4 av[4];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) av[k4] = *reinterpret_cast<const f32x4 *>(ap + k4 * 4);
+            if (p.prec == 1) {                 // split16 input: [hi0-7][hi8-15][lo0-7][lo8-15] -> 16 fp32 values
+                const f16x8 h0 = __builtin_bit_cast(f16x8, av[0]), h1 = __builtin_bit_cast(f16x8, av[1]);
+                const f16x8 l0 = __builtin_bit_cast(f16x8, av[2]), l1 = __builtin_bit_cast(f16x8, av[3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    av[0][j] = (float)h0[j] + (float)l0[j];
+                    av[1][j] = (float)h0[4 + j] + (float)l0[4 + j];
+                    av[2][j] = (float)h1[j] + (float)l1[j];
+                    av[3][j] = (float)h1[4 + j] + (float)l1[4 + j];
+                }
+            }
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) {
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(ap + k4 * 4);
+                const f32x4 a = av[k4];
                 const cfloat_p wt = w + (((int64_t)(cb * 9 + tap) * 4 + k4) * p.Cout) * 4;   // [n][4], n = 0..COUT-1
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -172,8 +200,16 @@ __global__ __launch_bounds__(256) void tail_kernel(const ConvParams p, int y_pla
         for (int n = 0; n < COUT; ++n) {
             if (n >= y_planar_ch) break;
             float v = edge_act(acc[n] + (p.bias ? as_const(p.bias)[n] : 0.f), p.act);
-            if (p.epilogue == BSVD_EPI_RESID && n < p.resid_ch)
-                v = p.extra[(int64_t)f * p.extra_fs + opix * p.extra_ps + (int64_t)n * p.extra_cs] - v;
+            if (p.epilogue == BSVD_EPI_RESID && n < p.resid_ch) {
+                float base;
+                if (p.extra_split) {           // split16 NHWC base: channel n < 16 lives in chunk 0
+                    const _Float16 *e = reinterpret_cast<const _Float16 *>(p.extra + (int64_t)f * p.extra_fs + opix * p.extra_ps);
+                    base = (float)e[n] + (float)e[16 + n];
+                } else {
+                    base = p.extra[(int64_t)f * p.extra_fs + opix * p.extra_ps + (int64_t)n * p.extra_cs];
+                }
+                v = base - v;
+            }
             if (do_clamp) v = fminf(fmaxf(v, lo), hi);
             p.y[(int64_t)f * p.y_fs + n * plane + opix] = v;
         }

@@ -1,4 +1,4 @@
-// conv3x3_f32_mfma.hip -- exact-fp32 implicit-GEMM 3x3 convolution for gfx950 (MI355X).
+// conv3x3_mfma.hip -- implicit-GEMM 3x3 convolution for gfx950 (MI355X): exact-fp32 and split-fp16 (3-pass) MFMA modes.
 //
 //   y[f] = epilogue( act( conv3x3( gather(x[f-1], x[f], x[f+1], fold) ) + bias ) )
 //
@@ -27,6 +27,15 @@
 // a 16-byte read gives a lane 4 consecutive channels and MFMA j (0..3) uses k = 8g + 4(l>>5) + j on both
 // operands -- any K permutation is legal as long as A and B agree, so every operand read is 16 bytes wide.
 //
+// PREC = 1 (BSVD_F16X3, "split16"): the same data movement with every fp32 value carried as an fp16 pair
+// v = hi + lo (hi = fp16(v), lo = fp16(v - hi)).  A 16-channel chunk of a pixel is stored as [hi x16 | lo x16] in
+// the SAME 64 bytes the fp32 layout uses, weights are pre-split the same way, and each K=16 block issues three
+// v_mfma_f32_32x32x16_f16 (hi*hi + lo*hi + hi*lo, fp32 accumulate; the lo*lo term is ~2^-22 relative and dropped).
+// 16x the MFMA rate of the fp32 instruction for 3x the instructions; measured max-abs error vs the fp32 reference
+// 2-4e-5 on bsvd_c64 (same class as the exact path; plain fp16 gives 1-3e-2).  The epilogue transposes each
+// 32x32 accumulator tile through a wave-private LDS scratch so that every lane stores 8 channels of one pixel as
+// two 16-byte vectors (hi, lo).
+//
 // Reference ops replaced: see include/bsvd_hip.h (bsvd_conv3x3).
 #include "bsvd_internal.h"
 
@@ -35,6 +44,7 @@ namespace bsvd {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 template <int TH_, int WM_, int WN_, int STRIDE_>
 struct ConvCfg {
@@ -146,8 +156,8 @@ struct ChunkSrc {          // wave-uniform description of one 16-channel chunk's
 };
 
 // ------------------------------------------------------------------------------------------------------
-template <class C, bool FAST>
-__global__ __launch_bounds__(256, C::OCC) void conv3x3_f32_kernel(const ConvParams p)
+template <class C, bool FAST, int PREC>
+__global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *const patch_buf = smem;                              // 2 x PATCH_FLOATS
@@ -202,6 +212,20 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_f32_kernel(const ConvPara
                 a[mt][g] = *reinterpret_cast<const f32x4 *>(ap + (2 * mt * C::STRIDE * C::PW) * C::PS + g * 8);
     };
     auto mfma32 = [&](const f32x4 (&a)[2][2], const f32x4 (&b)[2][2]) {
+        if constexpr (PREC == 1) {
+            // split16: a[mt][0] = 8 hi halves, a[mt][1] = 8 lo halves of this lane's k-slots; same for b[nt][.]
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const f16x8 ah = __builtin_bit_cast(f16x8, a[mt][0]), al = __builtin_bit_cast(f16x8, a[mt][1]);
+                    const f16x8 bh = __builtin_bit_cast(f16x8, b[nt][0]), bl = __builtin_bit_cast(f16x8, b[nt][1]);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[mt][nt], 0, 0, 0);
+                }
+            return;
+        }
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -369,6 +393,77 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_f32_kernel(const ConvPara
         }
     }
 
+    if constexpr (PREC == 1) {
+        // ---- split16 epilogue: per 32x32 accumulator tile, transpose through a wave-private LDS scratch
+        //      ([32 px][32 ch + 4 pad] floats; the patch buffers are free after the last chunk's barrier), then every
+        //      lane finishes 8 channels of one pixel: bias/act/epilogue in fp32, split into (hi, lo), two 16-B stores.
+        float *sc = smem + wid * (32 * 36);
+        const int Cq = p.Cout >> 2;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[mt][nt][r];
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int idx = lane + 64 * it;
+                    const int m = idx >> 2, q = idx & 3;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8 + 4);
+                    const int oy = oy0 + 4 * wm + 2 * mt + (m >> 4);
+                    const int ox = ox0 + (m & 15);
+                    const int n8 = n0 + wn * 64 + nt * 32 + q * 8;
+                    if (oy >= p.Ho || ox >= p.Wo || n8 >= p.Cout) continue;
+                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    if (p.bias) {
+                        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(p.bias + n8);
+                        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(p.bias + n8 + 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], p.act);
+                    float *dst;
+                    if (p.epilogue == BSVD_EPI_PS_ADD) {
+                        const int sub = n8 / Cq, ch8 = n8 - sub * Cq;
+                        const int64_t opix = (int64_t)(2 * oy + (sub >> 1)) * (2 * p.Wo) + (2 * ox + (sub & 1));
+                        const int coff = (ch8 >> 4) * 16 + ((ch8 >> 3) & 1) * 4;       // floats: chunk base + 8-ch half
+                        if (p.extra) {                                                // skip tensor: split16, same layout as y
+                            const float *e = p.extra + (int64_t)f * p.extra_fs + opix * p.extra_ps + coff;
+                            const f16x8 eh = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(e));
+                            const f16x8 el = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(e + 8));
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] += (float)eh[j] + (float)el[j];
+                        }
+                        dst = p.y + (int64_t)f * p.y_fs + opix * Cq + coff;
+                    } else {
+                        const int64_t opix = (int64_t)oy * p.Wo + ox;
+                        if (p.epilogue == BSVD_EPI_RESID && n8 == 0) {                 // base: fp32 with generic strides
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (j < p.resid_ch)
+                                    v[j] = p.extra[(int64_t)f * p.extra_fs + opix * p.extra_ps + (int64_t)j * p.extra_cs] - v[j];
+                        }
+                        dst = p.y + (int64_t)f * p.y_fs + opix * p.Cout + (n8 >> 4) * 16 + ((n8 >> 3) & 1) * 4;
+                    }
+                    f16x8 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        hi[j] = (_Float16)v[j];
+                        lo[j] = (_Float16)(v[j] - (float)hi[j]);
+                    }
+                    *reinterpret_cast<f32x4 *>(dst) = __builtin_bit_cast(f32x4, hi);
+                    *reinterpret_cast<f32x4 *>(dst + 8) = __builtin_bit_cast(f32x4, lo);
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue.  C/D layout of 32x32 MFMA: col (n) = lane&31, row (m) = (r&3) + 8*(r>>2) + 4*(lane>>5);
     //      m -> pixel (row m>>4, col m&15) of the 2x16 pixel block of MFMA tile mt.
     const int Cq = p.Cout >> 2;   // PS_ADD: channels of the shuffled output
@@ -404,7 +499,7 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_f32_kernel(const ConvPara
     }
 }
 
-template <class C, bool FAST>
+template <class C, bool FAST, int PREC>
 static int launch_cfg(const ConvParams &pin, hipStream_t stream)
 {
     ConvParams p = pin;
@@ -415,12 +510,12 @@ static int launch_cfg(const ConvParams &pin, hipStream_t stream)
     if (nblk <= 0 || nblk > 0x7fffffff) { set_error("bsvd_conv3x3: grid of %lld workgroups", (long long)nblk); return -1; }
     static bool attr_done = false;   // benign race: the call is idempotent
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_f32_kernel<C, FAST>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_kernel<C, FAST, PREC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_f32_kernel<C, FAST>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv3x3_kernel<C, FAST, PREC>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -431,10 +526,14 @@ static int launch_pick(const ConvParams &p, hipStream_t stream)
     // 32-bit byte offsets inside one frame / the packed weights.  (ablate == 8: timing builds force GENERIC.)
     const bool fast = p.vec_ok && (p.fold & 15) == 0 && (int64_t)p.H * p.W * p.Cin * 4 < 0x7fffffffLL &&
                       (int64_t)p.Cin * 9 * p.Cout * 4 < 0x7fffffffLL && p.ablate != 8;
-    return fast ? launch_cfg<C, true>(p, stream) : launch_cfg<C, false>(p, stream);
+    if (p.prec == 1) {
+        if (!fast) { set_error("bsvd_conv3x3: BSVD_F16X3 needs fold %% 16 == 0 and 16-byte aligned operands"); return -17; }
+        return launch_cfg<C, true, 1>(p, stream);
+    }
+    return fast ? launch_cfg<C, true, 0>(p, stream) : launch_cfg<C, false, 0>(p, stream);
 }
 
-int launch_conv3x3_f32(const ConvParams &p, int stride, hipStream_t stream)
+int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream)
 {
     // Cout <= 64 (the 540x960-level layers of bsvd_c64): 256 px x 64 ch tiles; wider layers: 128 px x 128 ch.
     // Stride 2 always takes the 128 x 128 tile (its 17x33 input patch is what bounds LDS).

@@ -28,10 +28,15 @@ class PackedNet:
     """Device-resident pre-packed weights of every layer (one-time transform of the state_dict,
     cf. BSVD.load, bsvd_arch.py:462-474): {spec.key: (w_packed, bias_packed)}."""
 
-    def __init__(self, net, state, device):
+    def __init__(self, net, state, device, precision="fp32"):
         lib = require_hip()
         self.device = device
+        self.precision = precision
         self.tensors = {}
+        edge = set()
+        if precision == "f16x3":
+            # the edge layers run on the fp32 VALU kernels (planar in / planar out) and keep fp32 packs
+            edge = {net.layers[0].key, net.layers[-1].key}
         with torch.cuda.device(device):
             for sp in net.layers:
                 w = state[sp.key + ".weight"].detach().to(device=device, dtype=torch.float32).contiguous()
@@ -43,8 +48,9 @@ class PackedNet:
                 n = lib.bsvd_packed_weight_elems(sp.cin_pad, sp.cout_pad)
                 wp = torch.empty(n, dtype=torch.float32, device=device)
                 bp = torch.empty(sp.cout_pad, dtype=torch.float32, device=device)
+                dt = _lib.BSVD_F16X3 if (precision == "f16x3" and sp.key not in edge) else _lib.BSVD_F32
                 rc = lib.bsvd_pack_weights(w.data_ptr(), b.data_ptr() if b is not None else None, sp.cin, sp.cout,
-                                           sp.cin_pad, sp.cout_pad, 1 if sp.epilogue == EPI_PS_ADD else 0, _lib.BSVD_F32,
+                                           sp.cin_pad, sp.cout_pad, 1 if sp.epilogue == EPI_PS_ADD else 0, dt,
                                            wp.data_ptr(), bp.data_ptr(), _stream_ptr())
                 _lib.check(rc, "bsvd_pack_weights(%s)" % sp.key)
                 self.tensors[sp.key] = (wp, bp)
@@ -60,11 +66,15 @@ class HipExecutor:
         self.lib = require_hip()
         self.packed = packed
         self.device = packed.device
+        self.split = packed.precision == "f16x3"      # NHWC activations are split16 (hi|lo fp16 pairs per chunk)
+        self.dtype = _lib.BSVD_F16X3 if self.split else _lib.BSVD_F32
         self.launches = 0
 
     # -- layout at the clip boundary ------------------------------------------------------------
     def to_nhwc(self, x_nchw, c_pad):
         """[T,C,H,W] fp32 contiguous device tensor -> [T,H,W,c_pad]"""
+        if self.split:
+            raise NotImplementedError("precision='f16x3' enters/leaves through the planar edge layers only")
         T, C, H, W = x_nchw.shape
         x_nchw = x_nchw.contiguous()
         y = torch.empty((T, H, W, c_pad), dtype=torch.float32, device=x_nchw.device)
@@ -74,6 +84,8 @@ class HipExecutor:
         return y
 
     def to_nchw(self, x_nhwc, c, clamp=None):
+        if self.split:
+            raise NotImplementedError("precision='f16x3' enters/leaves through the planar edge layers only")
         T, H, W, c_pad = x_nhwc.shape
         y = torch.empty((T, c, H, W), dtype=torch.float32, device=x_nhwc.device)
         lo, hi = (0.0, 0.0) if clamp is None else clamp
@@ -152,6 +164,8 @@ class HipExecutor:
             a.extra = extra.data_ptr()
             a.extra_frame_stride = extra[0].numel()
             a.extra_pstride, a.extra_cstride = extra_pstride, extra_cstride
+            if self.split and y_planar is not None and extra_pstride != 1:
+                a.extra_split = 1           # the base of the last layer's residual is an engine (split16) tensor
         elif sp.epilogue == EPI_RESID:
             raise ValueError("%s: the residual layer needs its base tensor" % sp.key)
         a.resid_ch = min(3, sp.cout) if sp.epilogue == EPI_RESID else 0
@@ -160,7 +174,7 @@ class HipExecutor:
         a.frames, a.H, a.W = T, H, W
         a.Cin, a.Cout = sp.cin_pad, sp.cout_pad
         a.stride = sp.stride
-        a.act, a.epilogue, a.dtype = _lib.ACT[sp.act], sp.epilogue, _lib.BSVD_F32
+        a.act, a.epilogue, a.dtype = _lib.ACT[sp.act], sp.epilogue, self.dtype
         rc = self.lib.bsvd_conv3x3(ctypes.byref(a), _stream_ptr())
         _lib.check(rc, "bsvd_conv3x3(%s)" % sp.key)
         self.launches += 1

@@ -17,7 +17,9 @@
  *   - Activations are NHWC ("channels last"): element (f, y, x, c) of a clip lives at
  *         base + f*frame_stride + (y*W + x)*C + c        (strides in ELEMENTS)
  *     with C already padded by the caller to a multiple of 16 (padded channels hold zeros).
- *   - dtype: BSVD_F32 is the exact-fp32 mode (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain).
+ *   - dtype: BSVD_F32 is the exact-fp32 mode (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain); BSVD_F16X3 the
+ *     split-fp16 3-pass mode (see the enum).  In BSVD_F16X3 the edge layers convert: planar fp32 in -> split16,
+ *     split16 -> planar fp32 out; the packed weights of MFMA layers are split16 too (bsvd_pack_weights dtype).
  */
 #ifndef BSVD_HIP_H
 #define BSVD_HIP_H
@@ -28,9 +30,15 @@
 extern "C" {
 #endif
 
-#define BSVD_ABI_VERSION 2
+#define BSVD_ABI_VERSION 3
 
-enum { BSVD_F32 = 0, BSVD_F16 = 1 };                       /* dtype                                  */
+/* dtype.  BSVD_F32: exact fp32 (v_mfma_f32_32x32x2_f32).  BSVD_F16X3 ("split16"): every fp32 value v is carried as
+ * an fp16 pair hi = fp16(v), lo = fp16(v - hi); a 16-channel chunk of a pixel is stored as [hi x16 | lo x16] in the
+ * same 64 bytes the fp32 layout uses (so shapes, strides and halo offsets are identical), and each K = 16 block is
+ * three fp16 MFMAs (hi*hi + lo*hi + hi*lo, fp32 accumulate).  fp32-class accuracy (2-4e-5 max-abs on bsvd_c64) at
+ * several times the fp32-MFMA rate.  BSVD_F16 (plain fp16) is reserved and not implemented: it misses the 1e-3
+ * parity bar (1-3e-2 measured). */
+enum { BSVD_F32 = 0, BSVD_F16 = 1, BSVD_F16X3 = 2 };
 enum { BSVD_ACT_NONE = 0, BSVD_ACT_RELU = 1, BSVD_ACT_RELU6 = 2 }; /* get_act_function, bsvd_arch.py:185-192 */
 enum {
     BSVD_EPI_PLAIN = 0,   /* y = act(conv + bias)                                                     */
@@ -88,6 +96,8 @@ typedef struct BsvdConvArgs {
      *                    clamps to [y_lo, y_hi] (the callers' torch.clamp, validation_seq_infer.py:24). */
     int32_t x_planar_ch, y_planar_ch, y_clamp;
     float y_lo, y_hi;
+    int32_t extra_split;        /* BSVD_F16X3 + y_planar_ch: the RESID base `extra` is a split16 NHWC tensor (extra_pstride
+                                 * floats per pixel) instead of fp32 with generic strides                              */
 } BsvdConvArgs;
 
 int bsvd_abi_version(void);

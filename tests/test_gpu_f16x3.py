@@ -1,0 +1,140 @@
+"""Parity of the split-fp16 3-pass MFMA mode (BSVD_F16X3 / precision='f16x3') against the fp32 CPU oracle and the
+reference goldens.  Budget: north_star's 1e-3 max-abs; measured errors are printed (expected 2-5e-5, i.e. the same
+class as the exact-fp32 path)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, bsvd_keys, state_for, maxabs
+from oracle_exec import OracleExecutor
+from seeded import seeded_state
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3          # north_star budget
+TIGHT = 2e-4        # what the 3-pass split is expected to deliver on O(10) outputs
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def to_split(x):
+    """fp32 NHWC [..., C] -> split16 container: per 16-channel chunk [hi x16 | lo x16] fp16 in the same 64 bytes."""
+    *lead, C = x.shape
+    v = x.reshape(*lead, C // 16, 16)
+    hi = v.half()
+    lo = (v - hi.float()).half()
+    return torch.cat([hi, lo], dim=-1).contiguous().view(torch.float32).reshape(*lead, C)
+
+
+def from_split(s):
+    *lead, C = s.shape
+    h = s.contiguous().view(torch.float16).reshape(*lead, C // 16, 32)
+    return (h[..., :16].float() + h[..., 16:].float()).reshape(*lead, C)
+
+
+def test_split_codec_roundtrip():
+    x = torch.randn(2, 3, 5, 32) * 3
+    assert float((from_split(to_split(x)) - x).abs().max()) < 4e-6 * 3 * 4
+
+
+def _exec(net, st):
+    from bsvd_amd.engine import HipExecutor, PackedNet
+    return HipExecutor(PackedNet(net, {k: torch.as_tensor(v) for k, v in st.items()}, _dev(), "f16x3"))
+
+
+class _Net:
+    """three layers so that PackedNet treats only the first/last as fp32-packed edge layers"""
+
+    def __init__(self, sp):
+        from bsvd_amd.netspec import ConvSpec
+        self.layers = [ConvSpec("e0", "e0", 4, 16, 1, False, "none", 0), sp, ConvSpec("e1", "e1", 16, 3, 1, False, "none", 2)]
+
+
+CASES = [
+    # cin, cout, stride, tsm, act, epi, T, H, W
+    (64, 64, 1, False, "relu6", 0, 1, 33, 50),
+    (128, 128, 1, True, "relu6", 0, 3, 10, 19),
+    (256, 256, 1, True, "relu", 0, 2, 9, 17),
+    (64, 128, 2, False, "relu6", 0, 2, 20, 36),
+    (128, 256, 2, False, "relu6", 0, 1, 27, 43),
+    (256, 512, 1, False, "none", 1, 2, 9, 13),
+    (128, 256, 1, False, "none", 1, 1, 12, 20),
+    (64, 64, 1, False, "none", 2, 2, 12, 20),
+]
+
+
+@pytest.mark.parametrize("cin,cout,stride,tsm,act,epi,T,H,W", CASES)
+def test_layer_split_vs_oracle(cin, cout, stride, tsm, act, epi, T, H, W):
+    from bsvd_amd.netspec import ConvSpec
+    from bsvd_amd.schedule import Halo
+    rs = np.random.RandomState(cin + cout + stride)
+    sp = ConvSpec("l", "l", cin, cout, stride, tsm, act, epi)
+    st = seeded_state([("e0.weight", (16, 4, 3, 3)), ("e0.bias", (16,)), ("l.weight", (cout, cin, 3, 3)),
+                       ("l.bias", (cout,)), ("e1.weight", (3, 16, 3, 3)), ("e1.bias", (3,))], 7)
+    gex, oex = _exec(_Net(sp), st), OracleExecutor(st, double=True)
+    x = torch.from_numpy(rs.standard_normal((T, H, W, cin)).astype(np.float32))
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    extra = extra_dev = None
+    eps, ecs = 0, 1
+    if epi == 1:
+        extra = torch.from_numpy(rs.standard_normal((T, 2 * Ho, 2 * Wo, cout // 4)).astype(np.float32))
+        extra = from_split(to_split(extra))            # what the engine would hold
+        extra_dev, eps = to_split(extra).to(_dev()), cout // 4
+    elif epi == 2:                                     # temp1's residual base: the planar fp32 network input
+        extra = torch.from_numpy(rs.standard_normal((T, 4, Ho, Wo)).astype(np.float32))
+        extra_dev, eps, ecs = extra.to(_dev()), 1, Ho * Wo
+    xq = from_split(to_split(x))                       # the oracle sees exactly the values the split input encodes
+    halos = [(None, None)]
+    if tsm:
+        fold = sp.fold
+        hp = from_split(to_split(torch.from_numpy(rs.standard_normal((H, W, fold)).astype(np.float32))))
+        hn = from_split(to_split(torch.from_numpy(rs.standard_normal((H, W, fold)).astype(np.float32))))
+        halos.append((Halo(hp, fold, 0), Halo(hn, fold, 0)))
+    for hp, hn in halos:
+        want = oex.conv(sp, xq, hp, hn, extra, eps, ecs)
+        d = lambda h: None if h is None else Halo(to_split(h.t).to(_dev()), h.pstride, h.coff)
+        got = from_split(gex.conv(sp, to_split(x).to(_dev()), d(hp), d(hn), extra_dev, eps, ecs).cpu())
+        err = maxabs(got.numpy(), want.numpy())
+        print("layer %s max-abs %.3e (|y| max %.1f)" % ((cin, cout, stride, tsm, epi), err, float(want.abs().max())))
+        assert err < TIGHT
+
+
+def _module(st, mode="clip"):
+    import bsvd_amd
+    m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, in_ch=4, out_ch=3, norm="none", act="relu6", interm_ch=64,
+                      pretrain_ckpt=None, engine_mode=mode, precision="f16x3")
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
+    return m.to(_dev())
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_golden_c64_split(tag):
+    g = load_golden("g5_bsvd_c64_" + tag)
+    st = state_for(g, bsvd_keys([64, 128, 256], 64, 4, 3, 64))
+    x = torch.from_numpy(g["x"]).to(_dev())
+    yc = _module(st)(x)
+    err = maxabs(yc.cpu().numpy(), g["out"])
+    print("g5_%s f16x3 max-abs vs reference golden: %.3e" % (tag, err))
+    assert err < TOL and err < TIGHT
+    if tag != "b":
+        ys = _module(st, "stream")(x)
+        assert torch.equal(ys, yc), "clip and stream schedules are bit-identical in split mode too"
+
+
+def test_full_resolution_split_vs_oracle_and_fp32_path():
+    from oracle import bsvd_oracle as O
+    from seeded import seeded_clip
+    st = seeded_state(bsvd_keys([64, 128, 256], 64, 4, 3, 64), 11)
+    x = torch.from_numpy(seeded_clip((1, 2, 4, 540, 960), 12, kind="sigma30"))
+    y = _module(st)(x.to(_dev())).cpu()
+    want = O.bsvd_clip(x, O.to_torch_state(st))
+    err = maxabs(y.numpy(), want.numpy())
+    print("540x960 f16x3 max-abs vs fp32 CPU oracle: %.3e" % err)
+    assert err < TOL
+
+
+def test_split_mode_rejects_unsupported_nets():
+    import bsvd_amd
+    with pytest.raises(ValueError):
+        bsvd_amd.BSVD(chns=[32, 64, 128], mid_ch=32, norm="none", interm_ch=32, pretrain_ckpt=None, precision="f16x3")
