@@ -31,7 +31,7 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16 MFMA peak (same guide); f16x3 issues 3 MFMA FLOPs per algorithmic FLOP
-DEFAULT_PRECISION = "fp32"
+DEFAULT_PRECISION = "f16x3"
 H, W = 540, 960
 SIGMA = 30.0 / 255.0
 
@@ -80,11 +80,12 @@ class LaunchTimer:
     def detach(self):
         self.ex.conv = self._orig
 
-    @staticmethod
-    def variant(sp):
+    def variant(self, sp):
+        """Kernel instantiation bsvd_conv3x3 dispatches to (conv3x3_mfma.hip: launch_conv3x3), <MT,NT,WM,WN,STRIDE>."""
+        tag = "[f16x3]" if self.ex.split else "[f32]"
         if sp.stride == 2:
-            return "conv3x3_f32_kernel<8,2,2,2>"
-        return "conv3x3_f32_kernel<8,2,2,1>" if sp.cout_pad > 64 else "conv3x3_f32_kernel<16,4,1,1>"
+            return "conv3x3_kernel<2,2,2,2,2>" + tag
+        return ("conv3x3_kernel<2,2,2,2,1>" if sp.cout_pad > 64 else "conv3x3_kernel<2,2,4,1,1>") + tag
 
     def summary(self):
         agg = {}
@@ -174,53 +175,50 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)      # backend "nccl" is RCCL on ROCm
 
-    model = build_model(device, args.precision)
-    peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_F16_MFMA_TFLOPS
-    model.engine_mode = args.mode
     lq, nm = synth_clip(args.frames, 100 + rank, device)       # this rank's window of the 10*N-frame clip
     x = torch.cat([lq, nm], dim=2)[0].contiguous()             # [F,4,H,W] resident in HBM before timing
-
-    halo_fn = None
-    ex = model._executor(device)
-    if world > 1:
-        from bsvd_amd.dist import HaloExchanger
-        halo_fn = HaloExchanger(ex, rank, world)
-
-    def step():
-        if args.mode == "stream":
-            return model.streaming_forward(x)
-        return model.clip_forward(x, halo_fn)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            y = step()
-        barrier()
-        timer = LaunchTimer(ex)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            y = step()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        timer.detach()
-    assert tuple(y.shape) == (args.frames, 3, H, W) and bool(torch.isfinite(y).all())
+    def timed_run(precision, steps, warmup):
+        """W untimed + K timed steps of the hot path at `precision`; returns (model, max-over-ranks seconds, per-kernel
+        launch timings, last output)."""
+        model = build_model(device, precision)
+        model.engine_mode = args.mode
+        ex = model._executor(device)
+        halo_fn = None
+        if world > 1:
+            from bsvd_amd.dist import HaloExchanger
+            halo_fn = HaloExchanger(ex, rank, world)
 
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if dist is not None:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    elapsed = float(t_max.item())
+        def step():
+            if args.mode == "stream":
+                return model.streaming_forward(x)
+            return model.clip_forward(x, halo_fn)
 
-    if rank == 0:
-        total_frames = args.frames * world * args.steps
-        fps = total_frames / elapsed
-        flop_per_frame = 2.0 * model.net.macs_per_frame(H, W)
-        agg = timer.summary()
+        with torch.no_grad():
+            for _ in range(warmup):
+                y = step()
+            barrier()
+            timer = LaunchTimer(ex)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                y = step()
+            barrier()
+            dt = time.perf_counter() - t0
+            timer.detach()
+        assert tuple(y.shape) == (args.frames, 3, H, W) and bool(torch.isfinite(y).all())
+        t_max = torch.tensor([dt], dtype=torch.float64, device=device)
+        if dist is not None:
+            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        return model, float(t_max.item()), timer.summary(), y
+
+    def roofline_of(agg, precision, steps):
+        peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_F16_MFMA_TFLOPS
         dom = max(agg, key=lambda k: agg[k]["ms"])
-        conv_ms = sum(v["ms"] for v in agg.values())
         ach = agg[dom]["flop"] / (agg[dom]["ms"] * 1e-3) / 1e12
         traffic, traffic_src = None, None
         try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/make_traffic.py)
@@ -229,6 +227,29 @@ def main():
             traffic_src = "profiles/traffic.json (%s; %s)" % (tj["source"], tj["formula"])
         except (OSError, KeyError, ValueError):
             pass
+        return {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, separate passes)",
+                "traffic_source": traffic_src,
+                "note": ("algorithmic FLOP over the fp32-MFMA peak (v_mfma_f32_32x32x2_f32)" if precision == "fp32" else
+                         "algorithmic FLOP over the dense fp16-MFMA peak; the 3-pass split issues 3 MFMA FLOP per "
+                         "algorithmic FLOP, so MFMA-pipe utilisation = 3 x frac"),
+                "avg_launch_ms": agg[dom]["ms"] / agg[dom]["launches"], "launches": agg[dom]["launches"],
+                "all_conv_kernels": {k: {"ms_per_step": v["ms"] / steps, "tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12,
+                                         "launches_per_step": v["launches"] // steps} for k, v in agg.items()},
+                "conv_ms_per_step": sum(v["ms"] for v in agg.values()) / steps}
+
+    # ---- the timed job (headline) ...
+    model, elapsed, agg, y = timed_run(args.precision, args.steps, args.warmup)
+    # ---- ... and, outside it, the other arithmetic mode on the same clip for reference + a live parity figure
+    other = "fp32" if args.precision == "f16x3" else "f16x3"
+    _, elapsed_o, agg_o, y_o = timed_run(other, max(1, min(args.steps, 3)), 1)
+    steps_o = max(1, min(args.steps, 3))
+    parity = float((y.float() - y_o.float()).abs().max())
+
+    if rank == 0:
+        total_frames = args.frames * world * args.steps
+        fps = total_frames / elapsed
+        flop_per_frame = 2.0 * model.net.macs_per_frame(H, W)
         out = {
             "metric": "denoised frames/sec @540x960 sigma=30 (bsvd_c64 streaming bidirectional-buffer forward)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -241,19 +262,15 @@ def main():
                        "frames_per_gpu": args.frames, "parallelism": "frame-window x%d" % world,
                        "flop_per_frame": flop_per_frame},
             "path_tflops": fps * flop_per_frame / 1e12,
-            "path_frac_of_mfma_peak": fps * flop_per_frame / 1e12 / (peak * world),
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak,
-                         "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-                         "note": ("algorithmic FLOP over the fp32-MFMA peak (v_mfma_f32_32x32x2_f32)" if args.precision == "fp32" else
-                                  "algorithmic FLOP over the dense fp16-MFMA peak; the 3-pass split issues 3 MFMA FLOP "
-                                  "per algorithmic FLOP, so MFMA-pipe utilisation = 3 x frac"),
-                         "traffic_unit": "HBM bytes per launch (PMC, separate passes)", "traffic_source": traffic_src,
-                         "avg_launch_ms": agg[dom]["ms"] / agg[dom]["launches"], "launches": agg[dom]["launches"],
-                         "all_conv_kernels": {k: {"ms_per_step": v["ms"] / args.steps,
-                                                  "tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12,
-                                                  "launches_per_step": v["launches"] // args.steps}
-                                              for k, v in agg.items()},
-                         "conv_ms_per_step": conv_ms / args.steps},
+            "path_frac_of_mfma_peak": fps * flop_per_frame / 1e12 /
+                                      ((PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_F16_MFMA_TFLOPS) * world),
+            "roofline": roofline_of(agg, args.precision, args.steps),
+            "parity": {"max_abs_f16x3_vs_exact_fp32_on_this_clip": parity, "budget": 1e-3,
+                       "note": "north_star: <= 1e-3 max-abs vs the fp32 forward; tests/test_gpu_f16x3.py pins 3-6e-5 vs "
+                               "the reference goldens"},
+            "other_mode": {"dtype": "f32" if other == "fp32" else "f16x3", "value": args.frames * world * steps_o / elapsed_o,
+                           "unit": "frames/s", "steps": steps_o, "ms_per_step": elapsed_o / steps_o * 1e3,
+                           "roofline": roofline_of(agg_o, other, steps_o)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model)

@@ -46,12 +46,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int TH_, int WM_, int WN_, int STRIDE_>
+// MT x NT = 32x32 MFMA tiles per wave (a wave covers 2*MT rows x 16 cols of pixels and 32*NT channels),
+// WM x WN = waves per workgroup along pixels / channels, RING = depth of the weight register ring (2: one step
+// ahead, 3: two steps ahead).
+template <int MT_, int NT_, int WM_, int WN_, int STRIDE_, int RING_ = 3>
 struct ConvCfg {
-    static constexpr int TH = TH_, TW = 16, WM = WM_, WN = WN_, STRIDE = STRIDE_;
+    static constexpr int MT = MT_, NT = NT_, WM = WM_, WN = WN_, STRIDE = STRIDE_, RING = RING_;
+    static constexpr int TH = 2 * MT * WM, TW = 16;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(TH == 4 * WM, "a wave covers 4 rows x 16 cols");
-    static constexpr int BN = WN * 64;
+    static_assert(RING == 2 || RING == 3, "");
+    static constexpr int BN = WN * NT * 32;
     static constexpr int PH = (TH - 1) * STRIDE + 3;
     static constexpr int PW = (TW - 1) * STRIDE + 3;
     static constexpr int PS = 20;                      // floats per patch pixel
@@ -71,7 +75,8 @@ struct ConvCfg {
     static constexpr int NSLICE = (PH + ROWS_PER_SLICE - 1) / ROWS_PER_SLICE;
     static_assert(NSLICE <= 8, "slices are loaded at taps 0..7 and stored at taps 1..8");
     // workgroups per CU the LDS footprint admits (160 KiB) -> register budget for __launch_bounds__
-    static constexpr int OCC = LDS_BYTES > 80 * 1024 ? 1 : (LDS_BYTES > 53 * 1024 ? 2 : 3);
+    static constexpr int OCC_LDS = LDS_BYTES > 80 * 1024 ? 1 : (LDS_BYTES > 53 * 1024 ? 2 : 3);
+    static constexpr int OCC = (MT * NT >= 8 && OCC_LDS > 2) ? 2 : OCC_LDS;   // 128 accumulator registers -> <= 2 waves/SIMD
 };
 
 struct SrcSel {            // per-frame sources of the temporal-shift gather (wave uniform)
@@ -192,32 +197,32 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
     const int ncb = p.Cin >> 4;
 
     // A fragments: per-lane offset into the LDS patch (floats)
-    const int a_lane = (((4 * wm + (li >> 4)) * C::STRIDE) * C::PW + (li & 15) * C::STRIDE) * C::PS + lh * 4;
-    const int nb0 = n0 + wn * 64 + li;                           // this lane's output channel for nt = 0 (+32 for nt = 1)
+    const int a_lane = (((2 * C::MT * wm + (li >> 4)) * C::STRIDE) * C::PW + (li & 15) * C::STRIDE) * C::PS + lh * 4;
+    const int nb0 = n0 + wn * (C::NT * 32) + li;                 // this lane's output channel for nt = 0 (+32 per nt)
 
-    f32x16 acc[2][2];
+    f32x16 acc[C::MT][C::NT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    auto load_a = [&](const float *pc, int tap_off, f32x4 (&a)[2][2]) {
+    auto load_a = [&](const float *pc, int tap_off, f32x4 (&a)[C::MT][2]) {
         const float *ap = pc + a_lane + tap_off;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
             for (int g = 0; g < 2; ++g)
                 a[mt][g] = *reinterpret_cast<const f32x4 *>(ap + (2 * mt * C::STRIDE * C::PW) * C::PS + g * 8);
     };
-    auto mfma32 = [&](const f32x4 (&a)[2][2], const f32x4 (&b)[2][2]) {
+    auto mfma32 = [&](const f32x4 (&a)[C::MT][2], const f32x4 (&b)[C::NT][2]) {
         if constexpr (PREC == 1) {
             // split16: a[mt][0] = 8 hi halves, a[mt][1] = 8 lo halves of this lane's k-slots; same for b[nt][.]
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
+                for (int nt = 0; nt < C::NT; ++nt) {
                     const f16x8 ah = __builtin_bit_cast(f16x8, a[mt][0]), al = __builtin_bit_cast(f16x8, a[mt][1]);
                     const f16x8 bh = __builtin_bit_cast(f16x8, b[nt][0]), bl = __builtin_bit_cast(f16x8, b[nt][1]);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[mt][nt], 0, 0, 0);
@@ -231,9 +236,9 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
+                    for (int nt = 0; nt < C::NT; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][g][j], b[nt][g][j], acc[mt][nt], 0, 0, 0);
     };
 
@@ -256,14 +261,17 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
         // weights: lane's byte offset inside a (chunk, tap) slab; the OOB sentinel masks columns >= Cout
         const unsigned slab_bytes = 64u * p.Cout;                // 4 k4 rows x Cout x 16 B
         const unsigned g_bytes = 32u * p.Cout;                   // k4 -> k4 + 2
-        const unsigned vb0 = nb0 < p.Cout ? (unsigned)(lh * p.Cout + nb0) * 16u : BSVD_OOB;
-        const unsigned vb1 = nb0 + 32 < p.Cout ? (unsigned)(lh * p.Cout + nb0 + 32) * 16u : BSVD_OOB;
-        auto load_b = [&](int step, f32x4 (&b)[2][2]) {
+        unsigned vb[C::NT];
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt)
+            vb[nt] = nb0 + 32 * nt < p.Cout ? (unsigned)(lh * p.Cout + nb0 + 32 * nt) * 16u : BSVD_OOB;
+        auto load_b = [&](int step, f32x4 (&b)[C::NT][2]) {
             const unsigned so = (unsigned)step * slab_bytes;
-            b[0][0] = buf_load4(rs_w, vb0, so);
-            b[1][0] = buf_load4(rs_w, vb1, so);
-            b[0][1] = buf_load4(rs_w, vb0, so + g_bytes);
-            b[1][1] = buf_load4(rs_w, vb1, so + g_bytes);
+#pragma unroll
+            for (int nt = 0; nt < C::NT; ++nt) {
+                b[nt][0] = buf_load4(rs_w, vb[nt], so);
+                b[nt][1] = buf_load4(rs_w, vb[nt], so + g_bytes);
+            }
         };
 
         // patch slices: thread = (row r3 inside a pass, column, channel quad)
@@ -293,9 +301,9 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
         };
 
         // ---- prologue: weights of steps 0 and 1 in flight, chunk 0 patch -> LDS
-        f32x4 b0[2][2], b1[2][2], b2[2][2];
+        f32x4 b0[C::NT][2], b1[C::NT][2], b2[C::NT][2];
         load_b(0, b0);
-        load_b(1, b1);
+        if constexpr (C::RING == 3) load_b(1, b1);
         {
             const ChunkSrc c = chunk_src(0);
             for (int row0 = 0; row0 < C::PH; row0 += C::ROWS_PER_SLICE) {
@@ -320,21 +328,33 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
 #pragma unroll 1
             for (int ky = 0; ky < 3; ++ky) {
                 // three taps per trip so that both register rings rotate statically:
-                //   weights  b0 -> b1 -> b2 (filled two steps ahead),  slices  s0 -> s1 -> s2 (stored one step later)
+                //   weights  b0 -> b1 -> b2 (filled RING-1 steps ahead),  slices  s0 -> s1 -> s2 (stored one step later)
 #define BSVD_TAP(KX, BCUR, BFILL, SNEW, SOLD)                                                                  \
                 {                                                                                              \
                     const int tap = ky * 3 + (KX);                                                             \
-                    f32x4 a[2][2];                                                                             \
+                    f32x4 a[C::MT][2];                                                                         \
                     load_a(pcur, (ky * C::PW + (KX)) * C::PS, a);                                              \
-                    load_b(step + 2 < nsteps ? step + 2 : nsteps - 1, BFILL);                                  \
+                    load_b(step + C::RING - 1 < nsteps ? step + C::RING - 1 : nsteps - 1, BFILL);              \
                     slice_load(cn, tap * C::ROWS_PER_SLICE, SNEW);   /* rows >= PH: OOB, zeros, never stored */ \
                     mfma32(a, BCUR);                                                                           \
                     if (tap >= 1 && tap <= C::NSLICE) slice_store(pnext, (tap - 1) * C::ROWS_PER_SLICE, SOLD); \
                     ++step;                                                                                    \
                 }
-                BSVD_TAP(0, b0, b2, s0, s2)
-                BSVD_TAP(1, b1, b0, s1, s0)
-                BSVD_TAP(2, b2, b1, s2, s1)
+                if constexpr (C::RING == 3) {
+                    BSVD_TAP(0, b0, b2, s0, s2)
+                    BSVD_TAP(1, b1, b0, s1, s0)
+                    BSVD_TAP(2, b2, b1, s2, s1)
+                } else {      // 2-deep ring: period 2 does not divide 3 taps -> alternate the roles by trip parity
+                    if (((cb + ky) & 1) == 0) {      // step parity: step = 9 cb + 3 ky + kx
+                        BSVD_TAP(0, b0, b1, s0, s2)
+                        BSVD_TAP(1, b1, b0, s1, s0)
+                        BSVD_TAP(2, b0, b1, s2, s1)
+                    } else {
+                        BSVD_TAP(0, b1, b0, s0, s2)
+                        BSVD_TAP(1, b0, b1, s1, s0)
+                        BSVD_TAP(2, b1, b0, s2, s1)
+                    }
+                }
 #undef BSVD_TAP
             }
             __syncthreads();   // one barrier per 16-channel chunk (9 taps, 288 MFMAs per wave)
@@ -342,19 +362,19 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
     } else {
         // ============================================================================= GENERIC path
         const int64_t slab_stride = (int64_t)16 * p.Cout;           // floats per (chunk, tap) weight slab
-        const bool nok0 = nb0 < p.Cout, nok1 = nb0 + 32 < p.Cout;
         const float *wl = p.w + ((int64_t)lh * p.Cout + nb0) * 4;
         const int64_t g_off = (int64_t)8 * p.Cout;
-        auto load_b = [&](int step, f32x4 (&b)[2][2]) {
+        auto load_b = [&](int step, f32x4 (&b)[C::NT][2]) {
             const float *sl = wl + (int64_t)step * slab_stride;
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                b[0][g] = nok0 ? *reinterpret_cast<const f32x4 *>(sl + g * g_off) : z;
-                b[1][g] = nok1 ? *reinterpret_cast<const f32x4 *>(sl + g * g_off + 128) : z;
-            }
+            for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    b[nt][g] = nb0 + 32 * nt < p.Cout ? *reinterpret_cast<const f32x4 *>(sl + g * g_off + 128 * nt) : z;
+                }
         };
-        f32x4 bcur[2][2], bnxt[2][2];
+        f32x4 bcur[C::NT][2], bnxt[C::NT][2];
         load_b(0, bcur);
         for (int e = tid; e < C::NQ; e += 256) store_patch_quad<C>(patch_buf, e, load_patch_quad<C>(p, s, 0, e, iy0, ix0));
         __syncthreads();
@@ -375,7 +395,7 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
                     if (do_p) preg[i] = load_patch_quad<C>(p, s, cb + 1, ep, iy0, ix0);
                 }
                 const int ky = tap / 3, kx = tap - ky * 3;
-                f32x4 a[2][2];
+                f32x4 a[C::MT][2];
                 load_a(pcur, (ky * C::PW + kx) * C::PS, a);
                 mfma32(a, bcur);
 #pragma unroll
@@ -385,7 +405,7 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
                     if (do_p) store_patch_quad<C>(pnext, ep, preg[i]);
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < C::NT; ++u)
 #pragma unroll
                     for (int g = 0; g < 2; ++g) bcur[u][g] = bnxt[u][g];
             }
@@ -400,9 +420,9 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
         float *sc = smem + wid * (32 * 36);
         const int Cq = p.Cout >> 2;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < C::MT; ++mt) {
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < C::NT; ++nt) {
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("" ::: "memory");
 #pragma unroll
@@ -415,9 +435,9 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
                     const int m = idx >> 2, q = idx & 3;
                     const f32x4 v0 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8);
                     const f32x4 v1 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8 + 4);
-                    const int oy = oy0 + 4 * wm + 2 * mt + (m >> 4);
+                    const int oy = oy0 + 2 * C::MT * wm + 2 * mt + (m >> 4);
                     const int ox = ox0 + (m & 15);
-                    const int n8 = n0 + wn * 64 + nt * 32 + q * 8;
+                    const int n8 = n0 + wn * (C::NT * 32) + nt * 32 + q * 8;
                     if (oy >= p.Ho || ox >= p.Wo || n8 >= p.Cout) continue;
                     float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     if (p.bias) {
@@ -468,16 +488,16 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
     //      m -> pixel (row m>>4, col m&15) of the 2x16 pixel block of MFMA tile mt.
     const int Cq = p.Cout >> 2;   // PS_ADD: channels of the shuffled output
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int n = n0 + wn * 64 + nt * 32 + li;
+    for (int nt = 0; nt < C::NT; ++nt) {
+        const int n = n0 + wn * (C::NT * 32) + nt * 32 + li;
         if (n >= p.Cout) continue;
         const float bias = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < C::MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int oy = oy0 + 4 * wm + 2 * mt + (m >> 4);
+                const int oy = oy0 + 2 * C::MT * wm + 2 * mt + (m >> 4);
                 const int ox = ox0 + (m & 15);
                 if (oy >= p.Ho || ox >= p.Wo) continue;
                 float v = apply_act(acc[mt][nt][r] + bias, p.act);
@@ -519,27 +539,36 @@ static int launch_cfg(const ConvParams &pin, hipStream_t stream)
     return (int)hipGetLastError();
 }
 
-template <class C>
-static int launch_pick(const ConvParams &p, hipStream_t stream)
+static bool fast_ok(const ConvParams &p)
 {
     // FAST needs: 16-B aligned vector gather (vec_ok), single-source 16-channel chunks (fold % 16 == 0) and
     // 32-bit byte offsets inside one frame / the packed weights.  (ablate == 8: timing builds force GENERIC.)
-    const bool fast = p.vec_ok && (p.fold & 15) == 0 && (int64_t)p.H * p.W * p.Cin * 4 < 0x7fffffffLL &&
-                      (int64_t)p.Cin * 9 * p.Cout * 4 < 0x7fffffffLL && p.ablate != 8;
-    if (p.prec == 1) {
-        if (!fast) { set_error("bsvd_conv3x3: BSVD_F16X3 needs fold %% 16 == 0 and 16-byte aligned operands"); return -17; }
-        return launch_cfg<C, true, 1>(p, stream);
-    }
-    return fast ? launch_cfg<C, true, 0>(p, stream) : launch_cfg<C, false, 0>(p, stream);
+    return p.vec_ok && (p.fold & 15) == 0 && (int64_t)p.H * p.W * p.Cin * 4 < 0x7fffffffLL &&
+           (int64_t)p.Cin * 9 * p.Cout * 4 < 0x7fffffffLL && p.ablate != 8;
+}
+
+template <class C>
+static int launch_f32(const ConvParams &p, hipStream_t stream)
+{
+    return fast_ok(p) ? launch_cfg<C, true, 0>(p, stream) : launch_cfg<C, false, 0>(p, stream);
 }
 
 int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream)
 {
-    // Cout <= 64 (the 540x960-level layers of bsvd_c64): 256 px x 64 ch tiles; wider layers: 128 px x 128 ch.
+    if (p.prec == 1) {
+        // split16: same tilings as fp32.  (Tried: 128-px wave tiles <4,2,2,2,1,2> -- 128 accumulator registers push
+        // the kernel past 256 VGPRs, scratch spills in the main loop, 10x slower; <4,1,2,2,1,3> for the 64-channel
+        // layers -- no gain over <2,2,4,1,1,3>.)
+        if (!fast_ok(p)) { set_error("bsvd_conv3x3: BSVD_F16X3 needs fold %% 16 == 0 and 16-byte aligned operands"); return -17; }
+        if (stride == 2) return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3>, true, 1>(p, stream);
+        return p.Cout > 64 ? launch_cfg<ConvCfg<2, 2, 2, 2, 1, 3>, true, 1>(p, stream)
+                           : launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1>(p, stream);
+    }
+    // exact fp32.  Cout <= 64 (the 540x960-level layers of bsvd_c64): 256 px x 64 ch tiles; wider layers: 128 px x 128 ch.
     // Stride 2 always takes the 128 x 128 tile (its 17x33 input patch is what bounds LDS).
     if (stride == 1)
-        return p.Cout > 64 ? launch_pick<ConvCfg<8, 2, 2, 1>>(p, stream) : launch_pick<ConvCfg<16, 4, 1, 1>>(p, stream);
-    return launch_pick<ConvCfg<8, 2, 2, 2>>(p, stream);
+        return p.Cout > 64 ? launch_f32<ConvCfg<2, 2, 2, 2, 1>>(p, stream) : launch_f32<ConvCfg<2, 2, 4, 1, 1>>(p, stream);
+    return launch_f32<ConvCfg<2, 2, 2, 2, 2>>(p, stream);
 }
 
 }  // namespace bsvd

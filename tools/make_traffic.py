@@ -4,7 +4,22 @@ FETCH_SIZE/WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 128-B req
 reads, hence the factor 2 (/opt/skills/guides/MI355X_MICROARCH.md, HBM section).  WRITE_SIZE calibrates 1:1 on this
 workload: the conv kernels' measured 597 MB/launch equals their algorithmic output bytes exactly.
 usage: make_traffic.py <pmc dir> <out json>"""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, json, os, re, sys
+
+
+def kernel_key(name):
+    """rocprof kernel name -> the variant names bench.py uses (LaunchTimer.variant)."""
+    m = re.search(r"conv3x3_kernel<bsvd::ConvCfg<(\d+), (\d+), (\d+), (\d+), (\d+), \d+>, (true|false), (\d)>", name)
+    if m:
+        mt, nt, wm, wn, st, fast, prec = m.groups()
+        return "conv3x3_kernel<%s,%s,%s,%s,%s>%s%s" % (mt, nt, wm, wn, st, "[f16x3]" if prec == "1" else "[f32]",
+                                                      "" if fast == "true" else "[generic]")
+    for k in ("head_kernel", "tail_kernel", "pack_weights_split_kernel", "pack_weights_kernel", "nchw_to_nhwc_kernel",
+              "nhwc_to_nchw_kernel", "halo_pack_kernel"):
+        if k in name:
+            return k
+    return name.split("(")[0]
+
 d, out = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
@@ -12,9 +27,7 @@ for f in sorted(glob.glob(os.path.join(d, "pass*", "*counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE") or "bsvd::" not in r["Kernel_Name"]:
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("bsvd::", "").replace("ConvCfg", "").replace(" ", "")
-        k = k.replace("<<", "<").replace(">,true>", ">").replace(">,false>", ">[generic]")   # bench.py's variant names
-        k = "head_kernel" if k.startswith("head_kernel") else ("tail_kernel" if k.startswith("tail_kernel") else k)
+        k = kernel_key(r["Kernel_Name"])
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[k][r["Counter_Name"]].add(r["Dispatch_Id"])
 res = {}
