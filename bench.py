@@ -85,7 +85,9 @@ class LaunchTimer:
         tag = "[f16x3]" if self.ex.split else "[f32]"
         if sp.stride == 2:
             return "conv3x3_kernel<2,2,2,2,2>" + tag
-        return ("conv3x3_kernel<2,2,2,2,1>" if sp.cout_pad > 64 else "conv3x3_kernel<2,2,4,1,1>") + tag
+        if sp.cout_pad <= 64:
+            return "conv3x3_kernel<2,2,4,1,1>" + tag
+        return ("conv3x3_kernel<4,2,2,2,1>" if self.ex.split else "conv3x3_kernel<2,2,2,2,1>") + tag
 
     def summary(self):
         agg = {}

@@ -20,6 +20,7 @@ namespace bsvd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // Weights/bias are read-only for the whole launch and indexed wave-uniformly: reading them through the constant
 // address space lets the compiler use scalar loads (SGPR operands) even with stores in the same loop.
 typedef const __attribute__((address_space(4))) float *cfloat_p;
@@ -135,11 +136,24 @@ __global__ __launch_bounds__(256) void tail_kernel(const ConvParams p, int y_pla
         g_off[i] = ok ? (iy * p.W + ix) * p.Cin + q * 4 : -1;      // < 2^31 elements per frame (checked by the host)
         l_off[i] = e < C::NQ ? pix * C::PS + q * 4 : -1;
     }
+    // split16 input: the item that would carry fp32 channels 4q..4q+3 instead reads the hi and lo halves of those
+    // channels (8 bytes each: hi at 2q*4 bytes, lo at 32 + 2q*4 bytes of the chunk) and rebuilds hi + lo, so the LDS
+    // patch always holds plain fp32 and every value is converted once, not once per tap.
     auto stage_load = [&](int cb, f32x4 (&v)[NI]) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (g_off[i] >= 0) v[i] = *reinterpret_cast<const f32x4 *>(xin + g_off[i] + cb * 16);
+            if (g_off[i] < 0) continue;
+            if (p.prec == 1) {
+                const int q = g_off[i] & 15;                                  // = 4 * quad index (elements)
+                const float *cbase = xin + (g_off[i] - q) + cb * 16;          // chunk base of this pixel
+                const f16x4 h = *reinterpret_cast<const f16x4 *>(reinterpret_cast<const _Float16 *>(cbase) + q);
+                const f16x4 l = *reinterpret_cast<const f16x4 *>(reinterpret_cast<const _Float16 *>(cbase) + 16 + q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[i][j] = (float)h[j] + (float)l[j];
+            } else {
+                v[i] = *reinterpret_cast<const f32x4 *>(xin + g_off[i] + cb * 16);
+            }
         }
     };
     auto stage_store = [&](float *buf, const f32x4 (&v)[NI]) {
@@ -167,17 +181,6 @@ __global__ __launch_bounds__(256) void tail_kernel(const ConvParams p, int y_pla
             f32x4 av[4];
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) av[k4] = *reinterpret_cast<const f32x4 *>(ap + k4 * 4);
-            if (p.prec == 1) {                 // split16 input: [hi0-7][hi8-15][lo0-7][lo8-15] -> 16 fp32 values
-                const f16x8 h0 = __builtin_bit_cast(f16x8, av[0]), h1 = __builtin_bit_cast(f16x8, av[1]);
-                const f16x8 l0 = __builtin_bit_cast(f16x8, av[2]), l1 = __builtin_bit_cast(f16x8, av[3]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    av[0][j] = (float)h0[j] + (float)l0[j];
-                    av[1][j] = (float)h0[4 + j] + (float)l0[4 + j];
-                    av[2][j] = (float)h1[j] + (float)l1[j];
-                    av[3][j] = (float)h1[4 + j] + (float)l1[4 + j];
-                }
-            }
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) {
                 const f32x4 a = av[k4];

@@ -49,8 +49,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // MT x NT = 32x32 MFMA tiles per wave (a wave covers 2*MT rows x 16 cols of pixels and 32*NT channels),
 // WM x WN = waves per workgroup along pixels / channels, RING = depth of the weight register ring (2: one step
 // ahead, 3: two steps ahead).
-template <int MT_, int NT_, int WM_, int WN_, int STRIDE_, int RING_ = 3>
+template <int MT_, int NT_, int WM_, int WN_, int STRIDE_, int RING_ = 3, bool DBUF_ = true>
 struct ConvCfg {
+    static constexpr bool DBUF = DBUF_;   // double-buffered LDS patch (next chunk prefetched during the taps)
     static constexpr int MT = MT_, NT = NT_, WM = WM_, WN = WN_, STRIDE = STRIDE_, RING = RING_;
     static constexpr int TH = 2 * MT * WM, TW = 16;
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -62,7 +63,8 @@ struct ConvCfg {
     static constexpr int NP = PH * PW;                 // patch pixels
     static constexpr int NQ = NP * 4;                  // float4 items per patch chunk
     static constexpr int PATCH_FLOATS = NP * PS;
-    static constexpr int LDS_BYTES = 2 * PATCH_FLOATS * 4;
+    static constexpr int LDS_BYTES = (DBUF ? 2 : 1) * PATCH_FLOATS * 4 < 4 * 32 * 36 * 4 ? 4 * 32 * 36 * 4
+                                                                                          : (DBUF ? 2 : 1) * PATCH_FLOATS * 4;
     // generic path: next patch spread over the 9 taps
     static constexpr int Q_PER_STEP = (NQ + 8) / 9;
     static constexpr int QG = (Q_PER_STEP + 255) / 256;          // items per thread per tap
@@ -76,7 +78,7 @@ struct ConvCfg {
     static_assert(NSLICE <= 8, "slices are loaded at taps 0..7 and stored at taps 1..8");
     // workgroups per CU the LDS footprint admits (160 KiB) -> register budget for __launch_bounds__
     static constexpr int OCC_LDS = LDS_BYTES > 80 * 1024 ? 1 : (LDS_BYTES > 53 * 1024 ? 2 : 3);
-    static constexpr int OCC = (MT * NT >= 8 && OCC_LDS > 2) ? 2 : OCC_LDS;   // 128 accumulator registers -> <= 2 waves/SIMD
+    static constexpr int OCC = (MT * NT >= 8) ? 1 : OCC_LDS;   // 128 accumulator registers: one wave per SIMD, 512 registers
 };
 
 struct SrcSel {            // per-frame sources of the temporal-shift gather (wave uniform)
@@ -317,8 +319,8 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
         const int nsteps = ncb * 9;
         int step = 0;
         for (int cb = 0; cb < ncb; ++cb) {
-            const float *pcur = patch_buf + (cb & 1) * C::PATCH_FLOATS;
-            float *pnext = patch_buf + ((cb + 1) & 1) * C::PATCH_FLOATS;
+            const float *pcur = patch_buf + (C::DBUF ? (cb & 1) * C::PATCH_FLOATS : 0);
+            float *pnext = patch_buf + (C::DBUF ? ((cb + 1) & 1) * C::PATCH_FLOATS : 0);
             // next chunk's source; after the last chunk a zero-size descriptor turns the slice loads into no-ops
             ChunkSrc cn = chunk_src(cb + 1 < ncb ? cb + 1 : cb);
             if (cb + 1 >= ncb) cn.rs = make_rsrc(s.cur, 0u);
@@ -335,9 +337,10 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
                     f32x4 a[C::MT][2];                                                                         \
                     load_a(pcur, (ky * C::PW + (KX)) * C::PS, a);                                              \
                     load_b(step + C::RING - 1 < nsteps ? step + C::RING - 1 : nsteps - 1, BFILL);              \
-                    slice_load(cn, tap * C::ROWS_PER_SLICE, SNEW);   /* rows >= PH: OOB, zeros, never stored */ \
+                    if constexpr (C::DBUF) slice_load(cn, tap * C::ROWS_PER_SLICE, SNEW);   /* rows >= PH: zeros */ \
                     mfma32(a, BCUR);                                                                           \
-                    if (tap >= 1 && tap <= C::NSLICE) slice_store(pnext, (tap - 1) * C::ROWS_PER_SLICE, SOLD); \
+                    if constexpr (C::DBUF)                                                                     \
+                        if (tap >= 1 && tap <= C::NSLICE) slice_store(pnext, (tap - 1) * C::ROWS_PER_SLICE, SOLD); \
                     ++step;                                                                                    \
                 }
                 if constexpr (C::RING == 3) {
@@ -358,6 +361,16 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
 #undef BSVD_TAP
             }
             __syncthreads();   // one barrier per 16-channel chunk (9 taps, 288 MFMAs per wave)
+            if constexpr (!C::DBUF) {
+                if (cb + 1 < ncb) {            // single buffer: everybody is done reading it -> refill, publish
+                    for (int row0 = 0; row0 < C::PH; row0 += C::ROWS_PER_SLICE) {
+                        f32x4 v[C::P];
+                        slice_load(cn, row0, v);
+                        slice_store(patch_buf, row0, v);
+                    }
+                }
+                __syncthreads();
+            }
         }
     } else {
         // ============================================================================= GENERIC path
@@ -556,19 +569,21 @@ static int launch_f32(const ConvParams &p, hipStream_t stream)
 int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream)
 {
     if (p.prec == 1) {
-        // split16: same tilings as fp32.  (Tried: 128-px wave tiles <4,2,2,2,1,2> -- 128 accumulator registers push
-        // the kernel past 256 VGPRs, scratch spills in the main loop, 10x slower; <4,1,2,2,1,3> for the 64-channel
-        // layers -- no gain over <2,2,4,1,1,3>.)
+        // split16.  Wide layers: 128-px x 64-ch wave tiles (half the weight bytes per MFMA, twice the step length) at ONE
+        // wave per SIMD with the full 512-register file: 430 vs 414 TFLOP/s for the 64x64 tile at 3 waves/SIMD.  (At 2
+        // waves/SIMD the same tile needs > 256 registers and spills in the main loop: 10x slower.  <4,1,2,2,1,3> for
+        // the 64-channel layers: no gain over <2,2,4,1,1,3>.)  Stride 2: single patch buffer -> 3 workgroups/CU
+        // instead of 1 (175 -> 287 TFLOP/s).
         if (!fast_ok(p)) { set_error("bsvd_conv3x3: BSVD_F16X3 needs fold %% 16 == 0 and 16-byte aligned operands"); return -17; }
-        if (stride == 2) return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3>, true, 1>(p, stream);
-        return p.Cout > 64 ? launch_cfg<ConvCfg<2, 2, 2, 2, 1, 3>, true, 1>(p, stream)
+        if (stride == 2) return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, false>, true, 1>(p, stream);
+        return p.Cout > 64 ? launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream)
                            : launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1>(p, stream);
     }
     // exact fp32.  Cout <= 64 (the 540x960-level layers of bsvd_c64): 256 px x 64 ch tiles; wider layers: 128 px x 128 ch.
-    // Stride 2 always takes the 128 x 128 tile (its 17x33 input patch is what bounds LDS).
+    // Stride 2 always takes the 128 x 128 tile with a single patch buffer (its 17x33 input patch is what bounds LDS).
     if (stride == 1)
         return p.Cout > 64 ? launch_f32<ConvCfg<2, 2, 2, 2, 1>>(p, stream) : launch_f32<ConvCfg<2, 2, 4, 1, 1>>(p, stream);
-    return launch_f32<ConvCfg<2, 2, 2, 2, 2>>(p, stream);
+    return launch_f32<ConvCfg<2, 2, 2, 2, 2, 3, false>>(p, stream);
 }
 
 }  // namespace bsvd

@@ -18,12 +18,13 @@ ap.add_argument("--size", type=int, nargs=2, default=[540, 960])
 ap.add_argument("--half", action="store_true", help="net_g.half() + autocast like profile.py:79-82 (I/O dtype only)")
 ap.add_argument("--mode", default="clip", choices=["clip", "stream"])
 ap.add_argument("--repeat", type=int, default=10)
+ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"])
 args = ap.parse_args()
 
 name = "BSVD" if "BSVD" in bsvd_amd.ARCH_REGISTRY else "BSVD_MI355X"
 net = bsvd_amd.build_network(dict(type=name, chns=[64, 128, 256], mid_ch=64, shift_input=False, in_ch=4, out_ch=3,
                                   norm="none", act="relu6", interm_ch=64, blind=False, pretrain_ckpt=None,
-                                  engine_mode=args.mode)).cuda().eval()
+                                  engine_mode=args.mode, precision=args.precision)).cuda().eval()
 inp = torch.randn(1, args.frames, 4, *args.size).cuda()
 if args.half:
     net, inp = net.half(), inp.half()
