@@ -381,6 +381,33 @@ def g8_pad_crop_clamp():
          seen_nm=np.array(dummy.seen[1]), seen_sigma=np.float32(dummy.seen[2]))
 
 
+def g9_psnr():
+    """calculate_psnr (uint8 domain) / calculate_psnr_float of the reference
+    (BasicSR/basicsr/metrics/psnr_ssim.py:9-45, 130-168) on a seeded pair with crop_border=2.
+    cv2 is absent in the container; it is only used by _ssim, so an empty stub module is enough here."""
+    import_reference()
+    for name in ("cv2", "basicsr.utils.matlab_functions"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.bgr2ycbcr = None
+            sys.modules[name] = m
+    if "basicsr.metrics" not in sys.modules or not hasattr(sys.modules["basicsr.metrics"], "__path__"):
+        mm = types.ModuleType("basicsr.metrics")
+        mm.__path__ = []
+        sys.modules["basicsr.metrics"] = mm
+    _load("basicsr.metrics.metric_util", os.path.join(REF, "BasicSR/basicsr/metrics/metric_util.py"))
+    ps = _load("basicsr.metrics.psnr_ssim", os.path.join(REF, "BasicSR/basicsr/metrics/psnr_ssim.py"))
+    rs = np.random.RandomState(901)
+    gt = rs.uniform(0, 1, (3, 16, 20)).astype(np.float32)
+    out = np.clip(gt + rs.standard_normal(gt.shape).astype(np.float32) * 0.05, 0, 1).astype(np.float32)
+    to_u8 = lambda a: (a.transpose(1, 2, 0)[..., ::-1] * 255.0).round().astype(np.uint8)   # HWC, BGR, rounded
+    p8 = ps.calculate_psnr(to_u8(out), to_u8(gt), crop_border=2)
+    pf = ps.calculate_psnr_float(torch.from_numpy(out), torch.from_numpy(gt), crop_border=2)
+    p8_nocrop = ps.calculate_psnr(to_u8(out), to_u8(gt), crop_border=0)
+    save("g9_psnr", gt=gt, out=out, psnr_u8=np.float64(p8), psnr_float=np.float64(pf), psnr_u8_nocrop=np.float64(p8_nocrop))
+    print("   psnr uint8 %.5f  float %.5f" % (p8, pf))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
@@ -394,6 +421,7 @@ def main():
     g6_blind()
     g7_ckpt_keymap(ref)
     g8_pad_crop_clamp()
+    g9_psnr()
 
 
 if __name__ == "__main__":
