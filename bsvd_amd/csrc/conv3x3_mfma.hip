@@ -576,8 +576,13 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream)
         // instead of 1 (175 -> 287 TFLOP/s).
         if (!fast_ok(p)) { set_error("bsvd_conv3x3: BSVD_F16X3 needs fold %% 16 == 0 and 16-byte aligned operands"); return -17; }
         if (stride == 2) return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, false>, true, 1>(p, stream);
-        return p.Cout > 64 ? launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream)
-                           : launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1>(p, stream);
+        // The fat tiles run one workgroup per CU, so they need a grid of several rounds of 256; small launches
+        // (streaming mode: one frame per launch) keep the 64x64 tiles at 3 workgroups per CU.
+        const int64_t fat_wide = (int64_t)p.frames * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16) * ((p.Cout + 127) / 128);
+        if (p.Cout > 64)
+            return fat_wide >= 1024 ? launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream)
+                                    : launch_cfg<ConvCfg<2, 2, 2, 2, 1, 3>, true, 1>(p, stream);
+        return launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1>(p, stream);   // (512-px fat tiles were tried: 9.6 vs 6.8 ms)
     }
     // exact fp32.  Cout <= 64 (the 540x960-level layers of bsvd_c64): 256 px x 64 ch tiles; wider layers: 128 px x 128 ch.
     // Stride 2 always takes the 128 x 128 tile with a single patch buffer (its 17x33 input patch is what bounds LDS).
