@@ -60,6 +60,7 @@ class LaunchTimer:
         self.ex = ex
         self.records = []
         self._orig = ex.conv
+        ex.record_variants = True
         ex.conv = self._conv
 
     def _conv(self, sp, x, *a, **k):
@@ -70,24 +71,15 @@ class LaunchTimer:
         e1.record()
         if k.get("x_planar"):
             T, _, Hh, Ww = x.shape
-            name = "head_kernel"
         else:
             T, Hh, Ww, _ = x.shape
-            name = "tail_kernel" if k.get("y_planar") is not None else self.variant(sp)
+        name = self.ex.last_variant          # kernel instantiation reported by the library (bsvd_conv3x3_variant)
         self.records.append((sp, T, Hh, Ww, e0, e1, name))
         return y
 
     def detach(self):
         self.ex.conv = self._orig
-
-    def variant(self, sp):
-        """Kernel instantiation bsvd_conv3x3 dispatches to (conv3x3_mfma.hip: launch_conv3x3), <MT,NT,WM,WN,STRIDE>."""
-        tag = "[f16x3]" if self.ex.split else "[f32]"
-        if sp.stride == 2:
-            return "conv3x3_kernel<2,2,2,2,2>" + tag
-        if sp.cout_pad <= 64:
-            return "conv3x3_kernel<2,2,4,1,1>" + tag
-        return ("conv3x3_kernel<4,2,2,2,1>" if self.ex.split else "conv3x3_kernel<2,2,2,2,1>") + tag
+        self.ex.record_variants = False
 
     def summary(self):
         agg = {}

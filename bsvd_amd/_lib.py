@@ -14,7 +14,7 @@ BSVD_F32, BSVD_F16, BSVD_F16X3 = 0, 1, 2
 ACT = {"none": 0, "relu": 1, "relu6": 2}
 EPI_PLAIN, EPI_PS_ADD, EPI_RESID = 0, 1, 2
 
-EXPORTS = ("bsvd_abi_version", "bsvd_conv_args_size", "bsvd_last_error", "bsvd_conv3x3", "bsvd_packed_weight_elems", "bsvd_pack_weights",
+EXPORTS = ("bsvd_abi_version", "bsvd_conv_args_size", "bsvd_last_error", "bsvd_conv3x3", "bsvd_conv3x3_variant", "bsvd_packed_weight_elems", "bsvd_pack_weights",
            "bsvd_nchw_to_nhwc", "bsvd_nhwc_to_nchw", "bsvd_halo_pack")
 
 
@@ -73,6 +73,8 @@ def load():
     lib.bsvd_last_error.argtypes = []
     lib.bsvd_conv3x3.restype = ctypes.c_int
     lib.bsvd_conv3x3.argtypes = [ctypes.POINTER(BsvdConvArgs), vp]
+    lib.bsvd_conv3x3_variant.restype = ctypes.c_int
+    lib.bsvd_conv3x3_variant.argtypes = [ctypes.POINTER(BsvdConvArgs), ctypes.c_char_p, i32]
     lib.bsvd_packed_weight_elems.restype = i64
     lib.bsvd_packed_weight_elems.argtypes = [i32, i32]
     lib.bsvd_pack_weights.restype = ctypes.c_int

@@ -164,7 +164,7 @@ const char *bsvd_last_error(void) { return g_err; }
 
 int64_t bsvd_packed_weight_elems(int32_t Cin_pad, int32_t Cout_pad) { return (int64_t)Cin_pad * 9 * Cout_pad; }
 
-int bsvd_conv3x3(const BsvdConvArgs *a, void *stream)
+static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int name_len)
 {
     if (!a) { set_error("bsvd_conv3x3: args is NULL"); return -1; }
     if (a->dtype != BSVD_F32 && a->dtype != BSVD_F16X3) { set_error("bsvd_conv3x3: dtype %d not supported (BSVD_F32, BSVD_F16X3)", a->dtype); return -2; }
@@ -222,13 +222,24 @@ int bsvd_conv3x3(const BsvdConvArgs *a, void *stream)
         if ((int64_t)a->H * a->W * (a->Cin > a->Cout ? a->Cin : a->Cout) >= 0x7fffffffLL) { set_error("bsvd_conv3x3: frame too large for the edge kernels"); return -16; }
         if (a->x_planar_ch > 0) {
             if (a->Cin != 16 || a->epilogue != BSVD_EPI_PLAIN) { set_error("bsvd_conv3x3: planar input needs Cin == 16 (padded) and the PLAIN epilogue"); return -16; }
+            if (name) { snprintf(name, name_len, "head_kernel<%d>%s", a->x_planar_ch, p.prec == 1 ? "[f16x3 out]" : "[f32]"); return 0; }
             return launch_head_f32(p, a->x_planar_ch, (hipStream_t)stream);
         }
         if (a->Cout != 16 || a->epilogue == BSVD_EPI_PS_ADD) { set_error("bsvd_conv3x3: planar output needs Cout == 16 (padded) and PLAIN/RESID"); return -16; }
         if (a->epilogue == BSVD_EPI_RESID && a->resid_ch > a->y_planar_ch) { set_error("bsvd_conv3x3: resid_ch > y_planar_ch"); return -16; }
+        if (name) { snprintf(name, name_len, "tail_kernel<%d>%s", a->y_planar_ch == 3 ? 3 : 4, p.prec == 1 ? "[f16x3 in]" : "[f32]"); return 0; }
         return launch_tail_f32(p, a->y_planar_ch, a->y_clamp, a->y_lo, a->y_hi, (hipStream_t)stream);
     }
-    return launch_conv3x3(p, a->stride, (hipStream_t)stream);
+    return launch_conv3x3(p, a->stride, (hipStream_t)stream, name, name_len);
+}
+
+int bsvd_conv3x3(const BsvdConvArgs *a, void *stream) { return conv3x3_impl(a, stream, nullptr, 0); }
+
+int bsvd_conv3x3_variant(const BsvdConvArgs *a, char *name, int32_t name_len)
+{
+    if (!name || name_len < 8) { set_error("bsvd_conv3x3_variant: name buffer too small"); return -1; }
+    name[0] = 0;
+    return conv3x3_impl(a, nullptr, name, name_len);
 }
 
 int bsvd_pack_weights(const float *w, const float *bias, int32_t Cin, int32_t Cout, int32_t Cin_pad, int32_t Cout_pad,

@@ -30,7 +30,8 @@ struct ConvParams {
 void set_error(const char *fmt, ...);
 
 // conv3x3_mfma.hip
-int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream);
+// name != nullptr: dry run, only writes the kernel instantiation that would be launched
+int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *name = nullptr, int name_len = 0);
 
 // conv3x3_edge_f32.hip
 int launch_head_f32(const ConvParams &p, int cin_real, hipStream_t stream);

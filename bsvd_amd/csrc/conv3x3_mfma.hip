@@ -37,6 +37,7 @@
 // two 16-byte vectors (hi, lo).
 //
 // Reference ops replaced: see include/bsvd_hip.h (bsvd_conv3x3).
+#include <stdio.h>
 #include "bsvd_internal.h"
 
 namespace bsvd {
@@ -533,8 +534,13 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
 }
 
 template <class C, bool FAST, int PREC>
-static int launch_cfg(const ConvParams &pin, hipStream_t stream)
+static int launch_cfg(const ConvParams &pin, hipStream_t stream, char *name = nullptr, int name_len = 0)
 {
+    if (name) {      // dry run: report the instantiation bsvd_conv3x3 would launch (used by bench.py's per-kernel timing)
+        snprintf(name, name_len, "conv3x3_kernel<%d,%d,%d,%d,%d>[%s]%s", C::MT, C::NT, C::WM, C::WN, C::STRIDE,
+                 PREC == 1 ? "f16x3" : "f32", FAST ? "" : "[generic]");
+        return 0;
+    }
     ConvParams p = pin;
     p.ntx = (p.Wo + C::TW - 1) / C::TW;
     p.nty = (p.Ho + C::TH - 1) / C::TH;
@@ -561,12 +567,12 @@ static bool fast_ok(const ConvParams &p)
 }
 
 template <class C>
-static int launch_f32(const ConvParams &p, hipStream_t stream)
+static int launch_f32(const ConvParams &p, hipStream_t stream, char *name, int name_len)
 {
-    return fast_ok(p) ? launch_cfg<C, true, 0>(p, stream) : launch_cfg<C, false, 0>(p, stream);
+    return fast_ok(p) ? launch_cfg<C, true, 0>(p, stream, name, name_len) : launch_cfg<C, false, 0>(p, stream, name, name_len);
 }
 
-int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream)
+int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *name, int name_len)
 {
     if (p.prec == 1) {
         // split16.  Wide layers: 128-px x 64-ch wave tiles (half the weight bytes per MFMA, twice the step length) at ONE
@@ -575,20 +581,20 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream)
         // the 64-channel layers: no gain over <2,2,4,1,1,3>.)  Stride 2: single patch buffer -> 3 workgroups/CU
         // instead of 1 (175 -> 287 TFLOP/s).
         if (!fast_ok(p)) { set_error("bsvd_conv3x3: BSVD_F16X3 needs fold %% 16 == 0 and 16-byte aligned operands"); return -17; }
-        if (stride == 2) return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, false>, true, 1>(p, stream);
+        if (stride == 2) return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, false>, true, 1>(p, stream, name, name_len);
         // The fat tiles run one workgroup per CU, so they need a grid of several rounds of 256; small launches
         // (streaming mode: one frame per launch) keep the 64x64 tiles at 3 workgroups per CU.
         const int64_t fat_wide = (int64_t)p.frames * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16) * ((p.Cout + 127) / 128);
         if (p.Cout > 64)
-            return fat_wide >= 1024 ? launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream)
-                                    : launch_cfg<ConvCfg<2, 2, 2, 2, 1, 3>, true, 1>(p, stream);
-        return launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1>(p, stream);   // (512-px fat tiles were tried: 9.6 vs 6.8 ms)
+            return fat_wide >= 1024 ? launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len)
+                                    : launch_cfg<ConvCfg<2, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
+        return launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1>(p, stream, name, name_len);   // (512-px fat tiles were tried: 9.6 vs 6.8 ms)
     }
     // exact fp32.  Cout <= 64 (the 540x960-level layers of bsvd_c64): 256 px x 64 ch tiles; wider layers: 128 px x 128 ch.
     // Stride 2 always takes the 128 x 128 tile with a single patch buffer (its 17x33 input patch is what bounds LDS).
     if (stride == 1)
-        return p.Cout > 64 ? launch_f32<ConvCfg<2, 2, 2, 2, 1>>(p, stream) : launch_f32<ConvCfg<2, 2, 4, 1, 1>>(p, stream);
-    return launch_f32<ConvCfg<2, 2, 2, 2, 2, 3, false>>(p, stream);
+        return p.Cout > 64 ? launch_f32<ConvCfg<2, 2, 2, 2, 1>>(p, stream, name, name_len) : launch_f32<ConvCfg<2, 2, 4, 1, 1>>(p, stream, name, name_len);
+    return launch_f32<ConvCfg<2, 2, 2, 2, 2, 3, false>>(p, stream, name, name_len);
 }
 
 }  // namespace bsvd

@@ -69,6 +69,8 @@ class HipExecutor:
         self.split = packed.precision == "f16x3"      # NHWC activations are split16 (hi|lo fp16 pairs per chunk)
         self.dtype = _lib.BSVD_F16X3 if self.split else _lib.BSVD_F32
         self.launches = 0
+        self.record_variants = False     # profiling aid: ask the library which kernel instantiation each conv uses
+        self.last_variant = None
 
     # -- layout at the clip boundary ------------------------------------------------------------
     def to_nhwc(self, x_nchw, c_pad):
@@ -175,6 +177,10 @@ class HipExecutor:
         a.Cin, a.Cout = sp.cin_pad, sp.cout_pad
         a.stride = sp.stride
         a.act, a.epilogue, a.dtype = _lib.ACT[sp.act], sp.epilogue, self.dtype
+        if self.record_variants:
+            buf = ctypes.create_string_buffer(96)
+            _lib.check(self.lib.bsvd_conv3x3_variant(ctypes.byref(a), buf, 96), "bsvd_conv3x3_variant(%s)" % sp.key)
+            self.last_variant = buf.value.decode()
         rc = self.lib.bsvd_conv3x3(ctypes.byref(a), _stream_ptr())
         _lib.check(rc, "bsvd_conv3x3(%s)" % sp.key)
         self.launches += 1

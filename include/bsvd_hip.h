@@ -104,8 +104,12 @@ int bsvd_abi_version(void);
 int bsvd_conv_args_size(void);   /* sizeof(BsvdConvArgs) as compiled into the library (binding sanity check) */
 const char *bsvd_last_error(void);
 
-/* The fused layer above.  Exact fp32 on MFMA (BSVD_F32). */
+/* The fused layer above (BSVD_F32: exact fp32 MFMA; BSVD_F16X3: split-fp16 3-pass MFMA). */
 int bsvd_conv3x3(const BsvdConvArgs *args, void *stream);
+
+/* Dry run: validates args exactly like bsvd_conv3x3 and writes the name of the kernel instantiation it would launch
+ * (e.g. "conv3x3_kernel<4,2,2,2,1>[f16x3]" = <MT,NT,WM,WN,STRIDE>) -- profiling aid, launches nothing. */
+int bsvd_conv3x3_variant(const BsvdConvArgs *args, char *name, int32_t name_len);
 
 /*
  * Re-orders one nn.Conv2d weight [Cout][Cin][3][3] (+ bias [Cout]) into the layout bsvd_conv3x3

@@ -55,6 +55,32 @@ def test_argument_validation_without_device():
         _lib.check(-5, "x")
 
 
+def test_variant_dry_run_reports_dispatch():
+    """bsvd_conv3x3_variant validates like bsvd_conv3x3 and names the kernel instantiation, launching nothing."""
+    from bsvd_amd import _lib
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(96)
+
+    def variant(**kw):
+        a = _lib.BsvdConvArgs()
+        a.x = a.y = a.w_packed = 256
+        a.frames, a.H, a.W, a.Cin, a.Cout, a.stride = 10, 270, 480, 128, 128, 1
+        for k, v in kw.items():
+            setattr(a, k, v)
+        rc = lib.bsvd_conv3x3_variant(ctypes.byref(a), buf, 96)
+        return rc, buf.value.decode()
+
+    assert variant() == (0, "conv3x3_kernel<2,2,2,2,1>[f32]")
+    assert variant(fold=16) == (0, "conv3x3_kernel<2,2,2,2,1>[f32]")
+    assert variant(fold=12) == (0, "conv3x3_kernel<2,2,2,2,1>[f32][generic]")
+    assert variant(dtype=_lib.BSVD_F16X3) == (0, "conv3x3_kernel<4,2,2,2,1>[f16x3]")
+    assert variant(dtype=_lib.BSVD_F16X3, frames=1) == (0, "conv3x3_kernel<2,2,2,2,1>[f16x3]")     # small grid: thin tiles
+    assert variant(Cout=64, H=540, W=960, Cin=64) == (0, "conv3x3_kernel<2,2,4,1,1>[f32]")
+    assert variant(stride=2, Cin=64) == (0, "conv3x3_kernel<2,2,2,2,2>[f32]")
+    assert variant(dtype=_lib.BSVD_F16X3, fold=12)[0] == -17
+    assert variant(Cin=12)[0] == -5
+
+
 def test_product_has_no_cpu_fallback():
     """Without a HIP device the product must fail loudly instead of computing on the CPU."""
     import torch

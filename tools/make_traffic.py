@@ -14,7 +14,10 @@ def kernel_key(name):
         mt, nt, wm, wn, st, fast, prec = m.groups()
         return "conv3x3_kernel<%s,%s,%s,%s,%s>%s%s" % (mt, nt, wm, wn, st, "[f16x3]" if prec == "1" else "[f32]",
                                                       "" if fast == "true" else "[generic]")
-    for k in ("head_kernel", "tail_kernel", "pack_weights_split_kernel", "pack_weights_kernel", "nchw_to_nhwc_kernel",
+    m = re.search(r"(head|tail)_kernel<(\d)>", name)
+    if m:
+        return m.group(0)          # bench.py appends the mode tag; match on the prefix
+    for k in ("pack_weights_split_kernel", "pack_weights_kernel", "nchw_to_nhwc_kernel",
               "nhwc_to_nchw_kernel", "halo_pack_kernel"):
         if k in name:
             return k
