@@ -9,7 +9,7 @@ import collections, csv, glob, json, os, re, sys
 
 def kernel_key(name):
     """rocprof kernel name -> the variant names bench.py uses (LaunchTimer.variant)."""
-    m = re.search(r"conv3x3_kernel<bsvd::ConvCfg<(\d+), (\d+), (\d+), (\d+), (\d+), \d+>, (true|false), (\d)>", name)
+    m = re.search(r"conv3x3_kernel<bsvd::ConvCfg<(\d+), (\d+), (\d+), (\d+), (\d+), \d+(?:, (?:true|false))?>, (true|false), (\d)>", name)
     if m:
         mt, nt, wm, wn, st, fast, prec = m.groups()
         return "conv3x3_kernel<%s,%s,%s,%s,%s>%s%s" % (mt, nt, wm, wn, st, "[f16x3]" if prec == "1" else "[f32]",
