@@ -49,8 +49,87 @@ def _denblock_params(chns, in_ch, out_ch, interm_ch, blind):
     )
 
 
+class _HipNet(nn.Module):
+    """Shared engine plumbing of the registered arch classes: NetSpec, precision, weight (re)packing, executor."""
+
+    def _init_engine(self, net, precision, clamp):
+        if precision not in ("fp32", "f16x3"):
+            raise ValueError("precision must be 'fp32' or 'f16x3'")
+        self.net = net
+        self.clamp = clamp
+        self.precision = precision
+        if precision == "f16x3":
+            bad = [l.key for l in net.layers[1:-1] if l.cin % 16 or l.cout % 16 or (l.tsm and l.fold % 16)]
+            if bad or net.net_in_ch not in (3, 4) or net.out_ch > 4:
+                raise ValueError("precision='f16x3' needs 16-aligned channel counts, fold % 16 == 0 (chns[1:] multiples "
+                                 "of 128) and <= 4 input/output channels; offending layers: %s" % (bad[:3],))
+        self._packed = None
+        self._packed_sig = None
+        self._exec = None
+
+    @staticmethod
+    def weight_init(m):
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, nonlinearity='relu')
+
+    def reset_params(self):
+        for m in self.modules():
+            self.weight_init(m)
+
+    def _engine_state(self):
+        """state_dict in BSVD key names (what netspec / PackedNet index by)."""
+        return self.state_dict()
+
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version, str(p.device), p.dtype) for p in self.parameters())
+
+    def _executor(self, device):
+        from .engine import HipExecutor, PackedNet, require_hip
+        require_hip()
+        sig = (self._signature(), str(device), self.precision)
+        if self._packed is None or self._packed_sig != sig:
+            self._packed = PackedNet(self.net, self._engine_state(), device, self.precision)
+            self._packed_sig = sig
+            self._exec = HipExecutor(self._packed)
+        return self._exec
+
+    def _device(self):
+        if not torch.cuda.is_available():
+            raise RuntimeError("bsvd_amd needs a HIP device (the reference hard-codes .cuda() too, "
+                               "bsvd_arch.py:94,104,520); no CPU fallback exists in the product path")
+        p = next(self.parameters())
+        return p.device if p.is_cuda else torch.device("cuda", torch.cuda.current_device())
+
+    def clip_forward(self, frames, halo_fn=None):
+        """frames: [T,C,H,W] -> [T,out_ch,H,W], layer-major over the whole clip."""
+        dev = self._device()
+        with torch.no_grad(), torch.cuda.device(dev):
+            ex = self._executor(dev)
+            out_dtype = frames.dtype if frames.dtype in (torch.float16, torch.bfloat16) else torch.float32
+            pin, pout = planar_ok(ex, self.net)
+            x = frames.to(device=dev, dtype=torch.float32).contiguous()
+            if not pin:
+                x = ex.to_nhwc(x, self.net.temp1["inc0"].cin_pad)
+            y = bsvd_clip(ex, self.net, x, halo_fn, x_planar=pin,
+                          y_planar=(self.net.out_ch, self.clamp) if pout else None)
+            if not pout:
+                y = ex.to_nchw(y, self.net.out_ch, self.clamp)
+            return y.to(out_dtype)
+
+    def _check_input(self, input, noise_map):
+        if noise_map is not None:
+            input = torch.cat([input, noise_map], dim=2)
+        C, H, W = input.shape[-3:]
+        if C != self.net.net_in_ch:
+            raise ValueError("expected %d input channels (incl. noise map), got %d" % (self.net.net_in_ch, C))
+        if H % 4 or W % 4:
+            raise ValueError("H and W must be multiples of 4 (two 2x scales); DenoisingModel pads the input "
+                             "(denoising_model.py:133-159), got %dx%d" % (H, W))
+        return input
+
+
 @register_arch
-class BSVD(nn.Module):
+class BSVD(_HipNet):
     """Bidirectional-buffer streaming video denoiser on MI355X.
 
     Reference arguments (bsvd_arch.py:446-447) keep their meaning and defaults.  Engine-only keywords:
@@ -75,69 +154,27 @@ class BSVD(nn.Module):
                                       "normalisation layers are not implemented by the MI355X engine" % (norm,))
         if engine_mode not in ("clip", "stream"):
             raise ValueError("engine_mode must be 'clip' or 'stream'")
-        if precision not in ("fp32", "f16x3"):
-            raise ValueError("precision must be 'fp32' or 'f16x3'")
-        self.net = make_netspec(chns, mid_ch, in_ch, out_ch, act, interm_ch, blind)
+        self._init_engine(make_netspec(chns, mid_ch, in_ch, out_ch, act, interm_ch, blind), precision, clamp)
         self.engine_mode = engine_mode
-        self.clamp = clamp
-        self.precision = precision
-        if precision == "f16x3":
-            n = self.net
-            bad = [l.key for l in n.layers[1:-1] if l.cin % 16 or l.cout % 16 or (l.tsm and l.fold % 16)]
-            if bad or n.net_in_ch not in (3, 4) or n.out_ch > 4:
-                raise ValueError("precision='f16x3' needs 16-aligned channel counts, fold % 16 == 0 (chns[1:] multiples "
-                                 "of 128) and <= 4 input/output channels; offending layers: %s" % (bad[:3],))
         self.temp1 = _denblock_params(self.net.chns, in_ch, mid_ch, interm_ch, blind)
         self.temp2 = _denblock_params(self.net.chns, mid_ch, out_ch, interm_ch, False)
         self.shift_num = self.net.shift_num
         self.reset_params()
-        self._packed = None
-        self._packed_sig = None
-        self._exec = None
         self._pipe = None
         if pretrain_ckpt is not None:
             self.load(pretrain_ckpt)
 
     # ---- parameters ----------------------------------------------------------------------------
-    @staticmethod
-    def weight_init(m):
-        if isinstance(m, nn.Conv2d):
-            nn.init.kaiming_normal_(m.weight, nonlinearity='relu')
-
-    def reset_params(self):
-        for m in self.modules():
-            self.weight_init(m)
-
     def load(self, path):
         ckpt = torch.load(path, map_location="cpu")
         print("load from %s" % path)
         state = ckpt['params'] if isinstance(ckpt, dict) and 'params' in ckpt else ckpt
         self.load_state_dict(checkpoint.to_bsvd_state(state))
 
-    def _signature(self):
-        return tuple((p.data_ptr(), p._version, str(p.device), p.dtype) for p in self.parameters())
-
-    def _executor(self, device):
-        from .engine import HipExecutor, PackedNet, require_hip
-        require_hip()
-        sig = (self._signature(), str(device), self.precision)
-        if self._packed is None or self._packed_sig != sig:
-            self._packed = PackedNet(self.net, self.state_dict(), device, self.precision)
-            self._packed_sig = sig
-            self._exec = HipExecutor(self._packed)
-        return self._exec
-
     # ---- streaming protocol (bsvd_arch.py:459-461, 485-488) --------------------------------------
     def reset(self):
         if self._pipe is not None:
             self._pipe.reset()
-
-    def _device(self):
-        if not torch.cuda.is_available():
-            raise RuntimeError("bsvd_amd.BSVD needs a HIP device (the reference hard-codes .cuda() too, "
-                               "bsvd_arch.py:94,104,520); no CPU fallback exists in the product path")
-        p = next(self.parameters())
-        return p.device if p.is_cuda else torch.device("cuda", torch.cuda.current_device())
 
     def feedin_one_element(self, x):
         """x: [1,C,H,W] tensor or None (flush).  Returns the frame fed ``shift_num`` steps earlier, or None."""
@@ -181,32 +218,10 @@ class BSVD(nn.Module):
         return torch.cat(outs[self.shift_num:], dim=0)
 
     # ---- clip forward (bsvd_arch.py:490-499) -----------------------------------------------------
-    def clip_forward(self, frames, halo_fn=None):
-        """frames: [T,C,H,W] -> [T,out_ch,H,W], layer-major over the whole clip."""
-        dev = self._device()
-        with torch.no_grad(), torch.cuda.device(dev):
-            ex = self._executor(dev)
-            out_dtype = frames.dtype if frames.dtype in (torch.float16, torch.bfloat16) else torch.float32
-            pin, pout = planar_ok(ex, self.net)
-            x = frames.to(device=dev, dtype=torch.float32).contiguous()
-            if not pin:
-                x = ex.to_nhwc(x, self.net.temp1["inc0"].cin_pad)
-            y = bsvd_clip(ex, self.net, x, halo_fn, x_planar=pin,
-                          y_planar=(self.net.out_ch, self.clamp) if pout else None)
-            if not pout:
-                y = ex.to_nchw(y, self.net.out_ch, self.clamp)
-            return y.to(out_dtype)
-
     def forward(self, input, noise_map=None):
         # N, F, C, H, W -> (N*F, C, H, W): like the reference, N>1 is one long clip
-        if noise_map is not None:
-            input = torch.cat([input, noise_map], dim=2)
+        input = self._check_input(input, noise_map)
         N, F, C, H, W = input.shape
-        if C != self.net.net_in_ch:
-            raise ValueError("expected %d input channels (incl. noise map), got %d" % (self.net.net_in_ch, C))
-        if H % 4 or W % 4:
-            raise ValueError("H and W must be multiples of 4 (two 2x scales); DenoisingModel pads the input "
-                             "(denoising_model.py:133-159), got %dx%d" % (H, W))
         frames = input.reshape(N * F, C, H, W)
         if self.engine_mode == "stream":
             out = self.streaming_forward(frames)
@@ -216,3 +231,87 @@ class BSVD(nn.Module):
 
     def count_shift(self):
         return self.net.shift_num
+
+
+def _tsn_denblock_params(chns, in_ch, out_ch, interm_ch, blind):
+    """Parameter holders under the TSN/WNet key names (wnet_models.py:126-170; TemporalShift wraps c1/c2 as `.net`)."""
+    c0, c1, c2 = chns
+    if blind:
+        in_ch = 3
+
+    def cv(c):
+        return _Slots(c1=_Slots(net=_conv(c, c)), c2=_Slots(net=_conv(c, c)))
+
+    return _Slots(
+        inc=_Slots(convblock=nn.ModuleDict({"0": _conv(in_ch, interm_ch), "3": _conv(interm_ch, c0)})),
+        downc0=_Slots(convblock=nn.ModuleDict({"0": _conv(c0, c1, 2), "3": cv(c1)})),
+        downc1=_Slots(convblock=nn.ModuleDict({"0": _conv(c1, c2, 2), "3": cv(c2)})),
+        upc2=_Slots(convblock=nn.ModuleDict({"0": cv(c2), "1": _conv(c2, 4 * c1)})),
+        upc1=_Slots(convblock=nn.ModuleDict({"0": cv(c1), "1": _conv(c1, 4 * c0)})),
+        outc=_Slots(convblock=nn.ModuleDict({"0": _conv(c0, c0), "3": _conv(c0, out_ch)})),
+    )
+
+
+class _QueueHalo:
+    """halo_fn of the MIMO mode: every temporal-fusion layer takes the slice the previous segment queued as its past
+    halo (segments after the first) and queues the [fold:2fold] slice of its last KEPT frame for the next segment --
+    batch_shift with enable_past_buffer (temporal_shift.py:53-80).  Future halo: zeros."""
+
+    def __init__(self, ex, enable_past_buffer):
+        self.ex, self.enable = ex, enable_past_buffer
+
+    def __call__(self, sp, v):
+        from . import global_queue_buffer as gq
+        from .schedule import Halo
+        if not self.enable:
+            return None, None
+        hp = Halo(gq.get(), sp.fold, 0) if gq.get_batch_index() > 0 else None
+        gq.put(self.ex.halo_pack(v[v.shape[0] - 1 - gq.get_future_buffer_length()], sp.fold, sp.fold))
+        return hp, None
+
+
+@register_arch
+class TSN(_HipNet):
+    """MIMO / segmented whole-clip inference of the same network (the training-time twin the reference evaluates the
+    blind checkpoint with): /root/reference/Experimental_root/archs/tsm_arch.py:11-74 + archs_2d/wnet_models.py:233-278 +
+    temporal_shift_ops/temporal_shift.py:6-80.  Inference only (eval-mode ``batch_shift`` semantics): the temporal shift
+    is zero padded inside each call; across the segments of ``denoise_seq`` the past slices travel through
+    ``bsvd_amd.global_queue_buffer``.  Parameters live under the TSN checkpoint key names
+    (``base_model.nets_list.{0,1}...``), so ``bsvd-64.pth``-style files load with ``load_state_dict`` directly."""
+
+    def __init__(self, num_segments=11, base_model='WNet_multistage', shift_type='TSM', shift_div=8, inplace=False,
+                 net2d_opt={}, enable_past_buffer=True, clamp=None, precision='fp32', **kwargs):
+        super().__init__()
+        if base_model != 'WNet_multistage':
+            raise NotImplementedError("base_model %r" % (base_model,))
+        if shift_type != 'TSM' or shift_div != 8:
+            raise NotImplementedError("only shift_type='TSM' with shift_div=8 is implemented (the shipped configs)")
+        o = dict(chns=[32, 64, 128], mid_ch=3, shift_input=False, stage_num=2, in_ch=4, out_ch=3, norm='bn', act='relu',
+                 interm_ch=30, blind=False)
+        o.update(net2d_opt)
+        if o['stage_num'] != 2 or o['shift_input'] or o['norm'] != 'none':
+            raise NotImplementedError("TSN on MI355X supports stage_num=2, shift_input=False, norm='none'")
+        self.num_segments = num_segments
+        self.enable_past_buffer = enable_past_buffer
+        self._init_engine(make_netspec(o['chns'], o['mid_ch'], o['in_ch'], o['out_ch'], o['act'], o['interm_ch'],
+                                       o['blind']), precision, clamp)
+        n = self.net
+        self.base_model = _Slots(nets_list=nn.ModuleList([
+            _tsn_denblock_params(n.chns, o['in_ch'], o['mid_ch'], o['interm_ch'], o['blind']),
+            _tsn_denblock_params(n.chns, o['mid_ch'], o['out_ch'], o['interm_ch'], False)]))
+        self.reset_params()
+
+    def _engine_state(self):
+        return checkpoint.to_bsvd_state(self.state_dict())
+
+    def forward(self, input, noise_map=None):
+        five_d = input.dim() == 5
+        if not five_d:
+            input = input[None]
+            noise_map = None if noise_map is None else noise_map[None]
+        input = self._check_input(input, noise_map)
+        N, F, C, H, W = input.shape
+        dev = self._device()
+        out = self.clip_forward(input.reshape(N * F, C, H, W), _QueueHalo(self._executor(dev), self.enable_past_buffer))
+        out = out.reshape(N, F, out.shape[1], H, W)
+        return out if five_d else out[0]

@@ -14,6 +14,7 @@ dumping of the reference class are out of scope.
 import torch
 import torch.nn.functional as F
 
+from . import global_queue_buffer
 from .registry import MODEL_REGISTRY, build_network
 
 
@@ -43,17 +44,28 @@ def denoise_seq(seq, noise_map, temp_psz, model_temporal, future_buffer_len=0):
         temp_psz = T                                   # BSVD: the whole video in a single forward
     out = torch.empty((T, C, H, W), dtype=torch.float32, device=seq.device)
     nseg = T // temp_psz
-    for i in range(nseg):
-        a, b = i * temp_psz, (i + 1) * temp_psz
-        b_in = b + future_buffer_len if b + future_buffer_len <= T else b
-        res = temp_denoise(model_temporal, seq[a:b_in].to(dev), noise_map, seq.device)
-        out[a:b] = res[:temp_psz]
-    rest = T - nseg * temp_psz
-    if rest > 0:
-        # mirror-extend the tail to a full segment, keep the first `rest` outputs (validation_seq_infer.py:75-90)
-        tail = torch.cat((seq[nseg * temp_psz:], torch.flip(seq[-(temp_psz - rest) - 1:-1], dims=[0])))
-        res = temp_denoise(model_temporal, tail.to(dev), noise_map, seq.device)
-        out[nseg * temp_psz:] = res[:rest]
+    # MIMO state (only TSN reads it; BSVD ignores it): per-layer past slices travel from segment to segment
+    global_queue_buffer._init(future_buffer_len)
+    try:
+        for i in range(nseg):
+            global_queue_buffer.set_batch_index(i)
+            a, b = i * temp_psz, (i + 1) * temp_psz
+            b_in = b + future_buffer_len
+            if b_in > T:                        # no look-ahead available for the last full segment
+                b_in = b
+                global_queue_buffer.set_future_buffer_length(0)
+            res = temp_denoise(model_temporal, seq[a:b_in].to(dev), noise_map, seq.device)
+            out[a:b] = res[:temp_psz]
+        global_queue_buffer.set_future_buffer_length(0)
+        rest = T - nseg * temp_psz
+        if rest > 0:
+            # mirror-extend the tail to a full segment, keep the first `rest` outputs (validation_seq_infer.py:75-90);
+            # like the reference the segment index is NOT advanced for the tail
+            tail = torch.cat((seq[nseg * temp_psz:], torch.flip(seq[-(temp_psz - rest) - 1:-1], dims=[0])))
+            res = temp_denoise(model_temporal, tail.to(dev), noise_map, seq.device)
+            out[nseg * temp_psz:] = res[:rest]
+    finally:
+        global_queue_buffer._clean()
     return out
 
 

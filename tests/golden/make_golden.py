@@ -408,6 +408,33 @@ def g9_psnr():
     print("   psnr uint8 %.5f  float %.5f" % (p8, pf))
 
 
+def g10_mimo_segments():
+    """MIMO / segmented inference of the reference: TSN (eval) driven by denoise_seq with temp_psz < T, look-ahead
+    frames and the global past-slice queue (validation_seq_infer.py:33-100, temporal_shift.py:53-80,
+    global_queue_buffer.py).  Cases: 2 full segments + mirrored tail with / without look-ahead; exactly one full
+    segment + tail (the tail then does NOT read the queued slices -- reference quirk)."""
+    tsm, gq = import_reference_tsn()
+    vsi, _ = import_reference_callers()
+    seed = 1001
+    net = tsm.TSN(num_segments=3, base_model="WNet_multistage", shift_type="TSM", shift_div=8,
+                  net2d_opt=dict(chns=[32, 64, 128], mid_ch=32, shift_input=False, stage_num=2, in_ch=4, out_ch=3,
+                                 norm="none", act="relu6", interm_ch=32, blind=False))
+    net.eval()
+    st = load_seeded(net, seed)
+    rs = np.random.RandomState(seed + 1)
+    arrays = {}
+    for tag, T, psz, fbl in (("a", 8, 3, 1), ("b", 8, 3, 0), ("c", 5, 3, 1), ("d", 6, 3, 2)):
+        seq = torch.from_numpy(rs.uniform(0, 1, (T, 3, 16, 24)).astype(np.float32))
+        nm = torch.full((T, 1, 16, 24), 30.0 / 255.0)
+        with torch.no_grad():
+            den = vsi.denoise_seq(seq, nm, psz, net, future_buffer_len=fbl)
+        arrays["seq_" + tag], arrays["den_" + tag] = t2n(seq), t2n(den)
+        arrays["cfg_" + tag] = np.array([T, psz, fbl])
+    save("g10_mimo_segments", seed=np.int64(seed), digest=np.array(state_digest(st)),
+         tsn_keys=np.array(list(st.keys())), tsn_shapes=np.array([",".join(map(str, v.shape)) for v in st.values()]),
+         **arrays)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
@@ -422,6 +449,7 @@ def main():
     g7_ckpt_keymap(ref)
     g8_pad_crop_clamp()
     g9_psnr()
+    g10_mimo_segments()
 
 
 if __name__ == "__main__":

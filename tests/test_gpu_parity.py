@@ -308,6 +308,43 @@ def test_denoising_model_pad_clamp_crop_end_to_end():
     assert maxabs(got.numpy(), want.numpy()) < TOL
 
 
+@pytest.mark.parametrize("tag", ["a", "c", "d"])
+def test_tsn_segmented_inference_on_gpu(tag):
+    """MIMO mode on the HIP engine: TSN + denoise_seq (segments, look-ahead, mirrored tail, queued past slices)."""
+    import bsvd_amd
+    from bsvd_amd.arch import TSN
+    g = load_golden("g10_mimo_segments")
+    st = seeded_state([(str(k), tuple(int(v) for v in str(s_).split(","))) for k, s_ in zip(g["tsn_keys"], g["tsn_shapes"])],
+                      int(g["seed"]))
+    m = TSN(num_segments=3, net2d_opt=dict(chns=[32, 64, 128], mid_ch=32, in_ch=4, out_ch=3, norm="none", act="relu6",
+                                           interm_ch=32, blind=False))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    m = m.to(_dev()).eval()
+    T, psz, fbl = (int(v) for v in g["cfg_" + tag])
+    seq = torch.from_numpy(g["seq_" + tag])
+    nm = torch.full((T, 1) + tuple(seq.shape[-2:]), 30.0 / 255.0)
+    den = bsvd_amd.denoise_seq(seq, nm, psz, m, future_buffer_len=fbl)
+    assert maxabs(den.numpy(), g["den_" + tag]) < TOL
+
+
+def test_tsn_blind_whole_clip_on_gpu():
+    """The blind c64 checkpoint schema through the TSN class (what the reference runs for blind denoising)."""
+    from bsvd_amd.arch import TSN
+    from bsvd_amd import global_queue_buffer as gq
+    g = load_golden("g6_blind_c64")
+    st = seeded_state([(str(k), tuple(int(v) for v in str(s_).split(","))) for k, s_ in zip(g["tsn_keys"], g["tsn_shapes"])],
+                      int(g["seed"]))
+    m = TSN(num_segments=5, net2d_opt=dict(chns=[64, 128, 256], mid_ch=64, in_ch=4, out_ch=3, norm="none", act="relu",
+                                           interm_ch=30, blind=True))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    m = m.to(_dev()).eval()
+    gq._init(0)
+    gq.set_batch_index(0)
+    y = m(torch.from_numpy(g["x"]).to(_dev()))
+    gq._clean()
+    assert maxabs(y.cpu().numpy(), g["out"]) < TOL
+
+
 def test_rejects_bad_arguments():
     from bsvd_amd import _lib
     import ctypes
