@@ -73,8 +73,12 @@ class _HipNet(nn.Module):
             nn.init.kaiming_normal_(m.weight, nonlinearity='relu')
 
     def reset_params(self):
-        for m in self.modules():
-            self.weight_init(m)
+        self._reset(self)
+
+    @classmethod
+    def _reset(cls, root):
+        for m in root.modules():
+            cls.weight_init(m)
 
     def _engine_state(self):
         """state_dict in BSVD key names (what netspec / PackedNet index by)."""
@@ -156,8 +160,13 @@ class BSVD(_HipNet):
             raise ValueError("engine_mode must be 'clip' or 'stream'")
         self._init_engine(make_netspec(chns, mid_ch, in_ch, out_ch, act, interm_ch, blind), precision, clamp)
         self.engine_mode = engine_mode
+        # Same RNG consumption as the reference constructor (each DenBlock re-initialises itself, then BSVD does it
+        # again, bsvd_arch.py:350,453): a seeded run draws the same weights AND leaves the generator in the same state,
+        # so the evaluation noise that follows (ValFolderDataset) is the reference's realisation.
         self.temp1 = _denblock_params(self.net.chns, in_ch, mid_ch, interm_ch, blind)
+        self._reset(self.temp1)
         self.temp2 = _denblock_params(self.net.chns, mid_ch, out_ch, interm_ch, False)
+        self._reset(self.temp2)
         self.shift_num = self.net.shift_num
         self.reset_params()
         self._pipe = None
@@ -296,9 +305,12 @@ class TSN(_HipNet):
         self._init_engine(make_netspec(o['chns'], o['mid_ch'], o['in_ch'], o['out_ch'], o['act'], o['interm_ch'],
                                        o['blind']), precision, clamp)
         n = self.net
-        self.base_model = _Slots(nets_list=nn.ModuleList([
-            _tsn_denblock_params(n.chns, o['in_ch'], o['mid_ch'], o['interm_ch'], o['blind']),
-            _tsn_denblock_params(n.chns, o['mid_ch'], o['out_ch'], o['interm_ch'], False)]))
+        stages = []
+        for args_ in ((o['in_ch'], o['mid_ch'], o['blind']), (o['mid_ch'], o['out_ch'], False)):
+            blk = _tsn_denblock_params(n.chns, args_[0], args_[1], o['interm_ch'], args_[2])
+            self._reset(blk)                      # wnet_models.DenBlock re-initialises itself, then WNet does (:139,:262)
+            stages.append(blk)
+        self.base_model = _Slots(nets_list=nn.ModuleList(stages))
         self.reset_params()
 
     def _engine_state(self):

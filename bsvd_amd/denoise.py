@@ -101,10 +101,25 @@ class DenoisingModel:
             raise RuntimeError("DenoisingModel needs a HIP device")
         self.device = torch.device("cuda")
         self.net_g = build_network(opt["network_g"]).to(self.device)
-        path = (opt.get("path") or {}).get("pretrain_network_g")
-        if path:
-            self.net_g.load(path)
+        popt = opt.get("path") or {}
+        if popt.get("pretrain_network_g"):
+            self.load_network(self.net_g, popt["pretrain_network_g"], popt.get("strict_load_g", True),
+                              popt.get("param_key_g", "params"))
         self.lq = self.gt = self.noise_map = self.output = None
+
+    @staticmethod
+    def load_network(net, load_path, strict=True, param_key="params"):
+        """BaseModel.load_network (BasicSR/basicsr/models/base_model.py:252-278): picks ``param_key``, strips the
+        DataParallel ``module.`` prefix; additionally a TSN-schema file is re-keyed when the target is ``BSVD``."""
+        from . import checkpoint
+        from .arch import BSVD
+        state = torch.load(load_path, map_location="cpu")
+        if param_key not in (None, "None") and isinstance(state, dict) and param_key in state:
+            state = state[param_key]
+        state = {(k[7:] if k.startswith("module.") else k): v for k, v in state.items()}
+        if isinstance(net, BSVD) and checkpoint.is_tsn_schema(state):
+            state = checkpoint.to_bsvd_state(state)
+        net.load_state_dict(state, strict=strict)
 
     def feed_data(self, data):
         self.lq = data["lq"].to(self.device)

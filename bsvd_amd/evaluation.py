@@ -102,16 +102,23 @@ def _crop(img, b):
     return img if b == 0 else img[b:-b, b:-b, ...]
 
 
-def calculate_psnr(img, img2, crop_border, input_order='HWC'):
+def _no_y(test_y_channel):
+    if test_y_channel:
+        raise NotImplementedError("test_y_channel=True is not used by the BSVD configs")
+
+
+def calculate_psnr(img, img2, crop_border, input_order='HWC', test_y_channel=False):
     """uint8-domain PSNR, range [0,255]."""
+    _no_y(test_y_channel)
     a = _crop(_hwc(np.asarray(img), input_order).astype(np.float64), crop_border)
     b = _crop(_hwc(np.asarray(img2), input_order).astype(np.float64), crop_border)
     mse = np.mean((a - b) ** 2)
     return float('inf') if mse == 0 else float(20. * np.log10(255. / np.sqrt(mse)))
 
 
-def calculate_psnr_float(img_float, img2_float, crop_border, input_order='CHW'):
+def calculate_psnr_float(img_float, img2_float, crop_border, input_order='CHW', test_y_channel=False):
     """float-domain PSNR, range [0,1] (the BSVD authors' addition)."""
+    _no_y(test_y_channel)
     a = _crop(_hwc(img_float.detach().cpu().numpy(), input_order), crop_border)
     b = _crop(_hwc(img2_float.detach().cpu().numpy(), input_order), crop_border)
     mse = np.mean((a - b) ** 2)
@@ -148,7 +155,8 @@ def _ssim(a, b):
     return float((((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 ** 2 + mu2 ** 2 + c1) * (s1 + s2 + c2))).mean())
 
 
-def calculate_ssim(img, img2, crop_border, input_order='HWC'):
+def calculate_ssim(img, img2, crop_border, input_order='HWC', test_y_channel=False):
+    _no_y(test_y_channel)
     a = _crop(_hwc(np.asarray(img), input_order).astype(np.float64), crop_border)
     b = _crop(_hwc(np.asarray(img2), input_order).astype(np.float64), crop_border)
     return float(np.mean([_ssim(a[..., i], b[..., i]) for i in range(a.shape[2])]))

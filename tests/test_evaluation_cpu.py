@@ -74,3 +74,21 @@ def test_val_folder_dataset(tmp_path):
     with Image.open(tmp_path / "a_clip" / "3.png") as im:
         assert np.array_equal((item["gt"][0, 3].numpy() * 255).round().astype(np.uint8), np.asarray(im).transpose(2, 0, 1))
     assert "noise_map" not in E.ValFolderDataset(dict(opt, blind=True), device=torch.device("cpu"))[1]
+
+
+def test_seeded_construction_matches_reference_rng_stream():
+    """Same weights and same generator state after construction as the reference classes (golden g11): a seeded
+    evaluation therefore adds the reference's noise realisation."""
+    from collections import OrderedDict
+    from seeded import state_digest
+    import bsvd_amd
+    from bsvd_amd.arch import TSN
+    g = load_golden("g11_seeded_init")
+    torch.manual_seed(123)
+    m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, norm="none", act="relu6", interm_ch=64, pretrain_ckpt=None)
+    assert state_digest(OrderedDict((k, v.numpy()) for k, v in m.state_dict().items())) == str(g["bsvd_digest"])
+    assert np.array_equal(torch.rand(4).numpy(), g["bsvd_next"])
+    torch.manual_seed(321)
+    t = TSN(num_segments=11, net2d_opt=dict(chns=[64, 128, 256], mid_ch=64, norm="none", act="relu", interm_ch=30, blind=True))
+    assert state_digest(OrderedDict((k, v.numpy()) for k, v in t.state_dict().items())) == str(g["tsn_digest"])
+    assert np.array_equal(torch.rand(4).numpy(), g["tsn_next"])

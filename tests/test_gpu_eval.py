@@ -1,0 +1,77 @@
+"""End-to-end evaluation harness on the GPU: tools/run_test.py on a synthetic image-folder dataset + a TSN-schema
+checkpoint file, checked against the CPU oracle pipeline fed with the same seeded noise."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+import yaml
+
+from helpers import bsvd_keys, maxabs
+from seeded import seeded_state
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_run_test_counterpart_end_to_end(tmp_path):
+    from PIL import Image
+    from oracle import bsvd_oracle as O
+    from bsvd_amd import evaluation as E
+    rs = np.random.RandomState(5)
+    clips = {}
+    for clip, n in (("clipA", 6), ("clipB", 4)):
+        os.makedirs(tmp_path / "data" / clip)
+        frames = rs.randint(0, 256, (n, 30, 50, 3)).astype(np.uint8)
+        clips[clip] = frames
+        for i in range(n):
+            Image.fromarray(frames[i]).save(tmp_path / "data" / clip / ("%05d.png" % i))
+    st = seeded_state(bsvd_keys([32, 64, 128], 32, 4, 3, 32), 31)
+    # the authors' checkpoints are TSN-schema: write one and load it through BSVD(pretrain_ckpt=...)
+    inv = {}
+    for k, v in st.items():
+        stage = "0" if k.startswith("temp1.") else "1"
+        t = k.split(".", 1)[1]
+        t = t.replace("downc0.memconv.", "downc0.convblock.3.").replace("downc1.memconv.", "downc1.convblock.3.")
+        if t.startswith("upc") and ".convblock.0." in t:
+            t = t.replace(".convblock.0.", ".convblock.1.")
+        t = t.replace("upc2.memconv.", "upc2.convblock.0.").replace("upc1.memconv.", "upc1.convblock.0.")
+        t = t.replace(".op.conv.", ".net.")
+        inv["module.base_model.nets_list.%s.%s" % (stage, t)] = torch.from_numpy(v)
+    ckpt = tmp_path / "tsn.pth"
+    torch.save({"params": inv}, ckpt)
+    opt = {"name": "t", "model_type": "DenoisingModel", "num_gpu": 1, "manual_seed": 10,
+           "datasets": {"val_1": {"name": "syn30", "type": "ValFolderDataset", "valsetdir": str(tmp_path / "data"),
+                                  "num_validation_frames": 5, "valnoisestd": 30}},
+           "network_g": {"type": "BSVD", "chns": [32, 64, 128], "mid_ch": 32, "shift_input": False, "norm": "none",
+                         "interm_ch": 32, "act": "relu6", "pretrain_ckpt": str(ckpt)},
+           "path": {"pretrain_network_g": None, "strict_load_g": True},
+           "val": {"temp_psz": -1, "future_buffer_len": 0,
+                   "metrics": {"psnr": {"type": "calculate_psnr", "crop_border": 2, "test_y_channel": False},
+                               "psnr_float": {"type": "calculate_psnr_float", "crop_border": 2, "test_y_channel": False},
+                               "ssim": {"type": "calculate_ssim", "crop_border": 2, "test_y_channel": False}}}}
+    yml = tmp_path / "opt.yml"
+    yml.write_text(yaml.safe_dump(opt))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_test.py"), "-opt", str(yml)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout[out.stdout.index("{\n"):])["syn30"]
+    # oracle pipeline with the same RNG stream: seed -> model construction (consumes RNG) -> per-clip noise in sorted order
+    import bsvd_amd
+    torch.manual_seed(10)
+    bsvd_amd.BSVD(chns=[32, 64, 128], mid_ch=32, norm="none", interm_ch=32, act="relu6", pretrain_ckpt=None)
+    P = O.to_torch_state(st)
+    cfg = O.default_cfg(chns=[32, 64, 128], mid_ch=32, interm_ch=32)
+    for clip in ("clipA", "clipB"):
+        gt = torch.from_numpy(np.float32(clips[clip][:5].transpose(0, 3, 1, 2) / 255.))[None]
+        noise = torch.FloatTensor(gt.size()).normal_(mean=0, std=30 / 255.0)
+        lq = F.pad((gt + noise)[0], (0, 2, 0, 2), mode="reflect")[None]
+        nm = torch.full((1, lq.shape[1], 1, 32, 52), 30 / 255.0)
+        den = O.bsvd_clip(lq, P, cfg, noise_map=nm).clamp(0, 1)[0, :, :, :30, :50]
+        want = np.mean([E.calculate_psnr(E.tensor2img(den[f]), E.tensor2img(gt[0, f]), 2) for f in range(den.shape[0])])
+        assert abs(res["folders"][clip]["psnr"] - want) < 2e-3, (clip, res["folders"][clip], want)
+    assert set(res["mean"]) == {"psnr", "psnr_float", "ssim"}
