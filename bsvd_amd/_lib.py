@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbsvd_hip.so")
+LIB_PATH = os.environ.get("BSVD_HIP_LIB") or os.path.join(_HERE, "libbsvd_hip.so")   # env override: A/B tuning builds
 
 ABI_VERSION = 3
 BSVD_F32, BSVD_F16, BSVD_F16X3 = 0, 1, 2

@@ -5,15 +5,17 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
-mkdir -p "$HERE/obj"
+OUT="${BSVD_OUT:-$ROOT/bsvd_amd/libbsvd_hip.so}"
+OBJ="$HERE/obj${BSVD_OBJ_SUFFIX:-}"
+mkdir -p "$OBJ"
 pids=()
 for src in conv3x3_mfma conv3x3_edge_f32 bsvd_abi; do
-  if [ ! -f "$HERE/obj/$src.o" ] || [ "$HERE/$src.hip" -nt "$HERE/obj/$src.o" ] || \
-     [ "$HERE/bsvd_internal.h" -nt "$HERE/obj/$src.o" ] || [ "$ROOT/include/bsvd_hip.h" -nt "$HERE/obj/$src.o" ]; then
-    $HIPCC $FLAGS ${EXTRA_HIPCC_FLAGS} -c "$HERE/$src.hip" -o "$HERE/obj/$src.o" &
+  if [ ! -f "$OBJ/$src.o" ] || [ "$HERE/$src.hip" -nt "$OBJ/$src.o" ] || \
+     [ "$HERE/bsvd_internal.h" -nt "$OBJ/$src.o" ] || [ "$ROOT/include/bsvd_hip.h" -nt "$OBJ/$src.o" ]; then
+    $HIPCC $FLAGS ${EXTRA_HIPCC_FLAGS} -c "$HERE/$src.hip" -o "$OBJ/$src.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$HERE"/obj/*.o -o "$ROOT/bsvd_amd/libbsvd_hip.so"
-echo "built $ROOT/bsvd_amd/libbsvd_hip.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -o "$OUT"
+echo "built $OUT"

@@ -18,7 +18,7 @@
 // FAST path (fold % 16 == 0, 16-B aligned operands; every bsvd_c64 layer): each 16-channel chunk has a
 // single temporal source, so all global reads are branch-free raw buffer loads (out-of-range lanes read 0
 // = zero padding / masking for free) and the weight fragments run TWO steps ahead in a 3-deep register
-// ring, the patch slices one step ahead in a second ring.  Measured on MI355X the memory latency seen by a
+// ring, the patch slices two steps ahead in a second ring.  Measured on MI355X the memory latency seen by a
 // wave under this load is several thousand cycles (PMC: 23 % of wave time parked in s_waitcnt with a 1-step
 // prefetch), which is what the deeper rings hide.  GENERIC path: any fold / alignment, per-element select.
 //
@@ -39,6 +39,14 @@
 // Reference ops replaced: see include/bsvd_hip.h (bsvd_conv3x3).
 #include <stdio.h>
 #include "bsvd_internal.h"
+
+// tuning knobs (compile-time; the defaults are the measured best)
+#ifndef BSVD_TUNE_ALIGN
+#define BSVD_TUNE_ALIGN 0      // 1: 256-B aligned LDS patch row pitch (conflict-free A reads)
+#endif
+#ifndef BSVD_TUNE_D
+#define BSVD_TUNE_D 1          // patch slices stored D (1|2) taps after their load was issued
+#endif
 
 namespace bsvd {
 
@@ -63,7 +71,13 @@ struct ConvCfg {
     static constexpr int PS = 20;                      // floats per patch pixel
     static constexpr int NP = PH * PW;                 // patch pixels
     static constexpr int NQ = NP * 4;                  // float4 items per patch chunk
-    static constexpr int PATCH_FLOATS = NP * PS;
+    // LDS row pitch of the patch.  Stride 1: rounded up to a multiple of 256 B so that the two pixel rows one
+    // ds_read_b128 lane group touches land on complementary 16-B slots (conflict-free A reads; PMC showed 48 % of the
+    // LDS cycles were bank conflicts with the packed 1440-B pitch).  Not for the 256-px x 64-ch tile at 3 workgroups
+    // per CU, whose double-buffered patch would no longer fit three times into 160 KiB.
+    static constexpr bool ALIGN_ROWS = BSVD_TUNE_ALIGN && STRIDE == 1 && !(MT == 2 && WM == 4);
+    static constexpr int ROWP = ALIGN_ROWS ? ((PW * PS * 4 + 255) / 256 * 256) / 4 : PW * PS;   // floats
+    static constexpr int PATCH_FLOATS = PH * ROWP;
     static constexpr int LDS_BYTES = (DBUF ? 2 : 1) * PATCH_FLOATS * 4 < 4 * 32 * 36 * 4 ? 4 * 32 * 36 * 4
                                                                                           : (DBUF ? 2 : 1) * PATCH_FLOATS * 4;
     // generic path: next patch spread over the 9 taps
@@ -76,7 +90,7 @@ struct ConvCfg {
     static constexpr int P = (PH + 8 * R - 1) / (8 * R);         // passes per slice so that <= 8 slices
     static constexpr int ROWS_PER_SLICE = R * P;
     static constexpr int NSLICE = (PH + ROWS_PER_SLICE - 1) / ROWS_PER_SLICE;
-    static_assert(NSLICE <= 8, "slices are loaded at taps 0..7 and stored at taps 1..8");
+    static_assert(NSLICE <= 7, "slices are loaded at taps 0..6 and stored two taps later (2..8)");
     // workgroups per CU the LDS footprint admits (160 KiB) -> register budget for __launch_bounds__
     static constexpr int OCC_LDS = LDS_BYTES > 80 * 1024 ? 1 : (LDS_BYTES > 53 * 1024 ? 2 : 3);
     static constexpr int OCC = (MT * NT >= 8) ? 1 : OCC_LDS;   // 128 accumulator registers: one wave per SIMD, 512 registers
@@ -133,7 +147,8 @@ template <class C>
 __device__ __forceinline__ void store_patch_quad(float *patch, int e, f32x4 v)
 {
     const int pix = e >> 2, q = e & 3;
-    *reinterpret_cast<f32x4 *>(patch + pix * C::PS + q * 4) = v;
+    const int py = pix / C::PW, px = pix - py * C::PW;
+    *reinterpret_cast<f32x4 *>(patch + py * C::ROWP + px * C::PS + q * 4) = v;
 }
 
 __device__ __forceinline__ float apply_act(float v, int act)
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
     const int ncb = p.Cin >> 4;
 
     // A fragments: per-lane offset into the LDS patch (floats)
-    const int a_lane = (((2 * C::MT * wm + (li >> 4)) * C::STRIDE) * C::PW + (li & 15) * C::STRIDE) * C::PS + lh * 4;
+    const int a_lane = ((2 * C::MT * wm + (li >> 4)) * C::STRIDE) * C::ROWP + ((li & 15) * C::STRIDE) * C::PS + lh * 4;
     const int nb0 = n0 + wn * (C::NT * 32) + li;                 // this lane's output channel for nt = 0 (+32 per nt)
 
     f32x16 acc[C::MT][C::NT];
@@ -217,7 +232,7 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
         for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
             for (int g = 0; g < 2; ++g)
-                a[mt][g] = *reinterpret_cast<const f32x4 *>(ap + (2 * mt * C::STRIDE * C::PW) * C::PS + g * 8);
+                a[mt][g] = *reinterpret_cast<const f32x4 *>(ap + (2 * mt * C::STRIDE) * C::ROWP + g * 8);
     };
     auto mfma32 = [&](const f32x4 (&a)[C::MT][2], const f32x4 (&b)[C::NT][2]) {
         if constexpr (PREC == 1) {
@@ -283,7 +298,7 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
         const bool t_ok = r3 < C::R;
         const int gx = ix0 + pcol;
         const bool x_ok = t_ok && gx >= 0 && gx < p.W;
-        const int lds_item = (r3 * C::PW + pcol) * C::PS + pq * 4;            // floats, pass row 0
+        const int lds_item = r3 * C::ROWP + pcol * C::PS + pq * 4;            // floats, pass row 0
         auto slice_load = [&](const ChunkSrc &c, int row0, f32x4 (&v)[C::P]) {
 #pragma unroll
             for (int i = 0; i < C::P; ++i) {
@@ -299,7 +314,7 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
             for (int i = 0; i < C::P; ++i) {
                 const int prow = row0 + i * C::R + r3;
                 if (t_ok && prow < C::PH)
-                    *reinterpret_cast<f32x4 *>(pb + lds_item + (row0 + i * C::R) * (C::PW * C::PS)) = v[i];
+                    *reinterpret_cast<f32x4 *>(pb + lds_item + (row0 + i * C::R) * C::ROWP) = v[i];
             }
         };
 
@@ -327,36 +342,46 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
             if (cb + 1 >= ncb) cn.rs = make_rsrc(s.cur, 0u);
             f32x4 s0[C::P], s1[C::P], s2[C::P];
 #pragma unroll
-            for (int i = 0; i < C::P; ++i) s2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < C::P; ++i) s1[i] = s2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int ky = 0; ky < 3; ++ky) {
                 // three taps per trip so that both register rings rotate statically:
-                //   weights  b0 -> b1 -> b2 (filled RING-1 steps ahead),  slices  s0 -> s1 -> s2 (stored one step later)
+                //   weights  b0 -> b1 -> b2 (filled RING-1 steps ahead),  slices  s0 -> s1 -> s2 (stored two steps later)
 #define BSVD_TAP(KX, BCUR, BFILL, SNEW, SOLD)                                                                  \
                 {                                                                                              \
                     const int tap = ky * 3 + (KX);                                                             \
                     f32x4 a[C::MT][2];                                                                         \
-                    load_a(pcur, (ky * C::PW + (KX)) * C::PS, a);                                              \
+                    load_a(pcur, ky * C::ROWP + (KX) * C::PS, a);                                              \
                     load_b(step + C::RING - 1 < nsteps ? step + C::RING - 1 : nsteps - 1, BFILL);              \
                     if constexpr (C::DBUF) slice_load(cn, tap * C::ROWS_PER_SLICE, SNEW);   /* rows >= PH: zeros */ \
                     mfma32(a, BCUR);                                                                           \
                     if constexpr (C::DBUF)                                                                     \
-                        if (tap >= 1 && tap <= C::NSLICE) slice_store(pnext, (tap - 1) * C::ROWS_PER_SLICE, SOLD); \
+                        if (tap >= BSVD_TUNE_D && tap <= C::NSLICE - 1 + BSVD_TUNE_D) slice_store(pnext, (tap - BSVD_TUNE_D) * C::ROWS_PER_SLICE, SOLD); \
                     ++step;                                                                                    \
                 }
+                // slice ring: loaded into slot tap%3, stored TWO taps later from slot (tap-2)%3 = (tap+1)%3
+#if BSVD_TUNE_D == 2
+#define S_OLD0 s1
+#define S_OLD1 s2
+#define S_OLD2 s0
+#else
+#define S_OLD0 s2
+#define S_OLD1 s0
+#define S_OLD2 s1
+#endif
                 if constexpr (C::RING == 3) {
-                    BSVD_TAP(0, b0, b2, s0, s2)
-                    BSVD_TAP(1, b1, b0, s1, s0)
-                    BSVD_TAP(2, b2, b1, s2, s1)
+                    BSVD_TAP(0, b0, b2, s0, S_OLD0)
+                    BSVD_TAP(1, b1, b0, s1, S_OLD1)
+                    BSVD_TAP(2, b2, b1, s2, S_OLD2)
                 } else {      // 2-deep ring: period 2 does not divide 3 taps -> alternate the roles by trip parity
                     if (((cb + ky) & 1) == 0) {      // step parity: step = 9 cb + 3 ky + kx
-                        BSVD_TAP(0, b0, b1, s0, s2)
-                        BSVD_TAP(1, b1, b0, s1, s0)
-                        BSVD_TAP(2, b0, b1, s2, s1)
+                        BSVD_TAP(0, b0, b1, s0, S_OLD0)
+                        BSVD_TAP(1, b1, b0, s1, S_OLD1)
+                        BSVD_TAP(2, b0, b1, s2, S_OLD2)
                     } else {
-                        BSVD_TAP(0, b1, b0, s0, s2)
-                        BSVD_TAP(1, b0, b1, s1, s0)
-                        BSVD_TAP(2, b1, b0, s2, s1)
+                        BSVD_TAP(0, b1, b0, s0, S_OLD0)
+                        BSVD_TAP(1, b0, b1, s1, S_OLD1)
+                        BSVD_TAP(2, b1, b0, s2, S_OLD2)
                     }
                 }
 #undef BSVD_TAP
@@ -410,7 +435,7 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
                 }
                 const int ky = tap / 3, kx = tap - ky * 3;
                 f32x4 a[C::MT][2];
-                load_a(pcur, (ky * C::PW + kx) * C::PS, a);
+                load_a(pcur, ky * C::ROWP + kx * C::PS, a);
                 mfma32(a, bcur);
 #pragma unroll
                 for (int i = 0; i < C::QG; ++i) {
