@@ -25,12 +25,14 @@ def shard_range(num_frames, world, rank):
 
 
 class _Pending:
-    def __init__(self, reqs, hp, hn):
-        self.reqs, self.hp, self.hn = reqs, hp, hn
+    def __init__(self, reqs, hp, hn, staged=()):
+        self.reqs, self.hp, self.hn, self.staged = reqs, hp, hn, staged
 
     def finish(self):
         for req in self.reqs:
             req.wait()          # NCCL/RCCL: orders the current stream after the transfer, no host sync
+        for host, dev in self.staged:          # host-staged backends (gloo has no device point-to-point)
+            dev.copy_(host, non_blocking=False)
         return self.hp, self.hn
 
 
@@ -42,6 +44,9 @@ class HaloExchanger:
         self.world = dist.get_world_size(group) if world is None else world
         self.bytes_sent = 0
         self.exchanges = 0
+        # gloo implements send/recv for CPU tensors only: stage device slices through the host there (tests, or a box
+        # without RCCL point-to-point).  RCCL ("nccl") moves device buffers directly over xGMI.
+        self.host_staging = dist.get_backend(group) == "gloo"
 
     def __call__(self, spec, v):
         """v: [T,H,W,C] input of temporal-fusion layer ``spec`` on this rank -> (Halo|None, Halo|None)."""
@@ -55,24 +60,35 @@ class HaloExchanger:
         if fold == 0 or not (has_left or has_right):
             return _Pending([], None, None)
         H, W = v.shape[1:3]
-        ops, recv_prev, recv_next = [], None, None
+        ops, recv_prev, recv_next, staged = [], None, None, []
+        stage = self.host_staging and v.is_cuda
+
+        def wire(t, receiving):
+            """tensor handed to the backend: the device buffer itself, or a host mirror when staging"""
+            if not stage:
+                return t
+            h = torch.empty(t.shape, dtype=t.dtype, device="cpu") if receiving else t.cpu()
+            if receiving:
+                staged.append((h, t))
+            return h
+
         if has_right:
             send_last = self.ex.halo_pack(v[-1], fold, fold)          # my last frame's [fold:2fold] -> right's halo_prev
             recv_next = torch.empty((H, W, fold), dtype=v.dtype, device=v.device)
-            ops += [dist.P2POp(dist.isend, send_last, self._peer(self.rank + 1), self.group),
-                    dist.P2POp(dist.irecv, recv_next, self._peer(self.rank + 1), self.group)]
+            ops += [dist.P2POp(dist.isend, wire(send_last, False), self._peer(self.rank + 1), self.group),
+                    dist.P2POp(dist.irecv, wire(recv_next, True), self._peer(self.rank + 1), self.group)]
             self.bytes_sent += send_last.numel() * send_last.element_size()
         if has_left:
             send_first = self.ex.halo_pack(v[0], 0, fold)             # my first frame's [0:fold] -> left's halo_next
             recv_prev = torch.empty((H, W, fold), dtype=v.dtype, device=v.device)
-            ops += [dist.P2POp(dist.isend, send_first, self._peer(self.rank - 1), self.group),
-                    dist.P2POp(dist.irecv, recv_prev, self._peer(self.rank - 1), self.group)]
+            ops += [dist.P2POp(dist.isend, wire(send_first, False), self._peer(self.rank - 1), self.group),
+                    dist.P2POp(dist.irecv, wire(recv_prev, True), self._peer(self.rank - 1), self.group)]
             self.bytes_sent += send_first.numel() * send_first.element_size()
         reqs = dist.batch_isend_irecv(ops)
         self.exchanges += 1
         hp = None if recv_prev is None else Halo(recv_prev, fold, 0)
         hn = None if recv_next is None else Halo(recv_next, fold, 0)
-        return _Pending(reqs, hp, hn)
+        return _Pending(reqs, hp, hn, staged)
 
     def _peer(self, group_rank):
         return group_rank if self.group is None else dist.get_global_rank(self.group, group_rank)
