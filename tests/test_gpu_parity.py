@@ -345,6 +345,43 @@ def test_tsn_blind_whole_clip_on_gpu():
     assert maxabs(y.cpu().numpy(), g["out"]) < TOL
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 4, 4, 4), (1, 2, 4, 8, 4), (2, 3, 4, 12, 20), (1, 1, 4, 4, 132)])
+def test_tiny_and_ragged_clips_vs_oracle(shape):
+    """Smallest legal frames (4x4: every level is a single masked tile), one-frame clips, N > 1 (the reference treats
+    the batch as one long clip, bsvd_arch.py:494-496), tiles with ragged right/bottom edges -- both arithmetic modes."""
+    from oracle import bsvd_oracle as O
+    from seeded import seeded_clip
+    st = seeded_state(bsvd_keys([64, 128, 256], 64, 4, 3, 64), 51)
+    x = torch.from_numpy(seeded_clip(shape, 52))
+    want = O.bsvd_clip(x, O.to_torch_state(st))
+    import bsvd_amd
+    for precision, tol in (("fp32", TOL), ("f16x3", 2e-4)):
+        for mode in ("clip", "stream"):
+            m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, norm="none", act="relu6", interm_ch=64, pretrain_ckpt=None,
+                              engine_mode=mode, precision=precision)
+            m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
+            y = m.to(_dev())(x.to(_dev()))
+            assert y.shape == want.shape
+            assert maxabs(y.cpu().numpy(), want.numpy()) < tol, (precision, mode)
+
+
+def test_half_io_like_profile_py():
+    """profile.py calls net_g.half() and feeds fp16 under autocast (profile.py:79-83): fp16 in, fp16 out, fp32 inside."""
+    import bsvd_amd
+    from oracle import bsvd_oracle as O
+    st = seeded_state(bsvd_keys([64, 128, 256], 64, 4, 3, 64), 53)
+    m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, norm="none", act="relu6", interm_ch=64, pretrain_ckpt=None)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
+    m = m.to(_dev()).half().eval()
+    x = torch.randn(1, 3, 4, 16, 24).half()
+    with torch.autocast("cuda", enabled=True):
+        y = m(x.to(_dev()))
+    assert y.dtype == torch.float16 and y.shape == (1, 3, 3, 16, 24)
+    P = {k: v.half().float() for k, v in O.to_torch_state(st).items()}        # .half() rounded the weights
+    want = O.bsvd_clip(x.float(), P)
+    assert maxabs(y.float().cpu().numpy(), want.numpy()) < 2e-2                # fp16 output rounding at |y| ~ 10
+
+
 def test_rejects_bad_arguments():
     from bsvd_amd import _lib
     import ctypes
