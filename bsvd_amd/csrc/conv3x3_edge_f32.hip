@@ -60,7 +60,14 @@ __global__ __launch_bounds__(256) void head_kernel(const ConvParams p)
             for (int c = 0; c < CIN; ++c) in[ky * 3 + kx][c] = ok ? xin[c * plane + (int64_t)iy * p.W + ix] : 0.f;
         }
 
-    float *yout = p.y + (int64_t)f * p.y_fs + ((int64_t)oy * p.W + ox) * p.Cout;
+    // Output staging: a thread owns one pixel, but 64-byte-per-lane stores at a 256-B lane stride reach HBM as partial
+    // lines (PMC: 1.6x the algorithmic bytes written).  Each wave therefore parks 32 output channels of its 64 pixels in
+    // a private LDS scratch ([px][32 + 4 pad] floats) and writes them back so that 8 consecutive lanes cover one pixel's
+    // 128 contiguous bytes (a full L2 line per 8 lanes).
+    __shared__ __attribute__((aligned(16))) float stage[4][64 * 36];
+    float *sc = stage[ty];
+    float *yrow = p.y + (int64_t)f * p.y_fs + ((int64_t)oy * p.W + (ox - tx)) * p.Cout;   // pixel 0 of this wave's row segment
+    const bool row_live = oy < p.H;
     const cfloat_p w = as_const(p.w);
     const cfloat_p bias = as_const(p.bias);
     for (int nb = 0; nb < p.Cout; nb += 16) {            // wave-uniform: weights below come through the scalar cache
@@ -75,7 +82,8 @@ __global__ __launch_bounds__(256) void head_kernel(const ConvParams p)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[j] = fmaf(in[tap][c], wt[j * 4 + c], acc[j]);
         }
-        if (live && p.prec == 1) {          // split16 output: [hi x16 | lo x16] in the chunk's 64 bytes
+        f32x4 o[4];
+        if (p.prec == 1) {                  // split16 output: [hi x16 | lo x16] in the chunk's 64 bytes
             f16x8 hi[2], lo[2];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -84,18 +92,32 @@ __global__ __launch_bounds__(256) void head_kernel(const ConvParams p)
                 hi[j >> 3][j & 7] = h;
                 lo[j >> 3][j & 7] = (_Float16)(v - (float)h);
             }
-            *reinterpret_cast<f32x4 *>(yout + nb) = __builtin_bit_cast(f32x4, hi[0]);
-            *reinterpret_cast<f32x4 *>(yout + nb + 4) = __builtin_bit_cast(f32x4, hi[1]);
-            *reinterpret_cast<f32x4 *>(yout + nb + 8) = __builtin_bit_cast(f32x4, lo[0]);
-            *reinterpret_cast<f32x4 *>(yout + nb + 12) = __builtin_bit_cast(f32x4, lo[1]);
-        } else if (live) {
+            o[0] = __builtin_bit_cast(f32x4, hi[0]); o[1] = __builtin_bit_cast(f32x4, hi[1]);
+            o[2] = __builtin_bit_cast(f32x4, lo[0]); o[3] = __builtin_bit_cast(f32x4, lo[1]);
+        } else {
 #pragma unroll
-            for (int j4 = 0; j4 < 4; ++j4) {
-                f32x4 v;
+            for (int j4 = 0; j4 < 4; ++j4)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = edge_act(acc[j4 * 4 + j], p.act);
-                *reinterpret_cast<f32x4 *>(yout + nb + j4 * 4) = v;
+                for (int j = 0; j < 4; ++j) o[j4][j] = edge_act(acc[j4 * 4 + j], p.act);
+        }
+        const int half = (nb >> 4) & 1;       // which 16-channel half of the 32-channel staging group
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) *reinterpret_cast<f32x4 *>(sc + tx * 36 + half * 16 + j4 * 4) = o[j4];
+        if (half == 1 || nb + 16 >= p.Cout) {              // group complete -> wave-private write-back
+            const int g0 = nb - half * 16;                  // first channel of the group
+            const int gq = (nb + 16 - g0) >> 2;             // float4 items per pixel in this group (4 or 8)
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int item = it * 64 + tx;
+                const int px = item >> 3, q = item & 7;
+                if (row_live && q < gq && bx * 64 + px < p.W)
+                    *reinterpret_cast<f32x4 *>(yrow + (int64_t)px * p.Cout + g0 + q * 4) =
+                        *reinterpret_cast<const f32x4 *>(sc + px * 36 + q * 4);
             }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
 }
