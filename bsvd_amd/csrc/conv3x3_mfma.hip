@@ -583,12 +583,12 @@ static int launch_cfg(const ConvParams &pin, hipStream_t stream, char *name = nu
     return (int)hipGetLastError();
 }
 
-static bool fast_ok(const ConvParams &p)
+static bool fast_ok(const ConvParams &p, bool honour_force_generic = true)
 {
     // FAST needs: 16-B aligned vector gather (vec_ok), single-source 16-channel chunks (fold % 16 == 0) and
     // 32-bit byte offsets inside one frame / the packed weights.  (ablate == 8: timing builds force GENERIC.)
     return p.vec_ok && (p.fold & 15) == 0 && (int64_t)p.H * p.W * p.Cin * 4 < 0x7fffffffLL &&
-           (int64_t)p.Cin * 9 * p.Cout * 4 < 0x7fffffffLL && p.ablate != 8;
+           (int64_t)p.Cin * 9 * p.Cout * 4 < 0x7fffffffLL && !(honour_force_generic && p.ablate == 8);
 }
 
 template <class C>
@@ -605,7 +605,7 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
         // waves/SIMD the same tile needs > 256 registers and spills in the main loop: 10x slower.  <4,1,2,2,1,3> for
         // the 64-channel layers: no gain over <2,2,4,1,1,3>.)  Stride 2: single patch buffer -> 3 workgroups/CU
         // instead of 1 (175 -> 287 TFLOP/s).
-        if (!fast_ok(p)) { set_error("bsvd_conv3x3: BSVD_F16X3 needs fold %% 16 == 0 and 16-byte aligned operands"); return -17; }
+        if (!fast_ok(p, false)) { set_error("bsvd_conv3x3: BSVD_F16X3 needs fold %% 16 == 0 and 16-byte aligned operands"); return -17; }
         if (stride == 2) return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, false>, true, 1>(p, stream, name, name_len);
         // The fat tiles run one workgroup per CU, so they need a grid of several rounds of 256; small launches
         // (streaming mode: one frame per launch) keep the 64x64 tiles at 3 workgroups per CU.
