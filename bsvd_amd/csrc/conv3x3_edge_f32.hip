@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void head_kernel(const ConvParams p)
             f16x8 hi[2], lo[2];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float v = edge_act(acc[j], p.act);
+                const float v = fminf(fmaxf(edge_act(acc[j], p.act), -65504.f), 65504.f);   // saturate, never inf/NaN pairs
                 const _Float16 h = (_Float16)v;
                 hi[j >> 3][j & 7] = h;
                 lo[j >> 3][j & 7] = (_Float16)(v - (float)h);

@@ -513,8 +513,9 @@ __global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p
                     f16x8 hi, lo;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        hi[j] = (_Float16)v[j];
-                        lo[j] = (_Float16)(v[j] - (float)hi[j]);
+                        const float vs = fminf(fmaxf(v[j], -65504.f), 65504.f);    // saturate instead of inf/NaN pairs
+                        hi[j] = (_Float16)vs;
+                        lo[j] = (_Float16)(vs - (float)hi[j]);
                     }
                     *reinterpret_cast<f32x4 *>(dst) = __builtin_bit_cast(f32x4, hi);
                     *reinterpret_cast<f32x4 *>(dst + 8) = __builtin_bit_cast(f32x4, lo);
