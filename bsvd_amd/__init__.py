@@ -7,5 +7,6 @@ from .registry import ARCH_REGISTRY, MODEL_REGISTRY, build_network  # noqa: F401
 from .arch import BSVD  # noqa: F401
 from .netspec import make_netspec  # noqa: F401
 from .denoise import DenoisingModel, denoise_seq, temp_denoise  # noqa: F401
+from .arch import TSN  # noqa: F401
 
 __version__ = "0.1.0"

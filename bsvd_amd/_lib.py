@@ -15,7 +15,7 @@ ACT = {"none": 0, "relu": 1, "relu6": 2}
 EPI_PLAIN, EPI_PS_ADD, EPI_RESID = 0, 1, 2
 
 EXPORTS = ("bsvd_abi_version", "bsvd_conv_args_size", "bsvd_last_error", "bsvd_conv3x3", "bsvd_conv3x3_variant", "bsvd_packed_weight_elems", "bsvd_pack_weights",
-           "bsvd_nchw_to_nhwc", "bsvd_nhwc_to_nchw", "bsvd_halo_pack")
+           "bsvd_nchw_to_nhwc", "bsvd_nhwc_to_nchw", "bsvd_halo_pack", "bsvd_u8_to_planar", "bsvd_planar_to_u8")
 
 
 class BsvdConvArgs(ctypes.Structure):
@@ -83,6 +83,10 @@ def load():
     lib.bsvd_nchw_to_nhwc.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.bsvd_nhwc_to_nchw.restype = ctypes.c_int
     lib.bsvd_nhwc_to_nchw.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp]
+    lib.bsvd_u8_to_planar.restype = ctypes.c_int
+    lib.bsvd_u8_to_planar.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]
+    lib.bsvd_planar_to_u8.restype = ctypes.c_int
+    lib.bsvd_planar_to_u8.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.bsvd_halo_pack.restype = ctypes.c_int
     lib.bsvd_halo_pack.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     if lib.bsvd_abi_version() != ABI_VERSION:

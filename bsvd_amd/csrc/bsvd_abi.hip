@@ -142,6 +142,36 @@ __global__ void halo_pack_kernel(const float *__restrict__ frame, float *__restr
     }
 }
 
+// uint8 frame I/O: HWC or planar uint8 -> planar fp32 in [0,1] (+ constant trailing channels, e.g. the
+// sigma map) and back with the reference's clamp + round-half-even (tensor2img, img_util.py:66,87-90)
+__global__ void u8_to_planar_kernel(const uint8_t *__restrict__ src, float *__restrict__ dst, int C, int Cout, int HW,
+                                    int hwc, float const_val, int64_t total)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i % HW;
+        const int64_t fc = i / HW;
+        const int c = (int)(fc % Cout);
+        const int64_t f = fc / Cout;
+        float v = const_val;
+        if (c < C) v = (float)src[hwc ? (f * HW + pix) * C + c : (f * C + c) * HW + pix] / 255.0f;
+        dst[i] = v;
+    }
+}
+
+__global__ void planar_to_u8_kernel(const float *__restrict__ src, uint8_t *__restrict__ dst, int C, int HW, int hwc,
+                                    int reverse_ch, int64_t total)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i % HW;
+        const int64_t fc = i / HW;
+        const int c = (int)(fc % C);
+        const int64_t f = fc / C;
+        const float v = fminf(fmaxf(src[i], 0.f), 1.f) * 255.0f;
+        const int co = reverse_ch ? C - 1 - c : c;
+        dst[hwc ? (f * HW + pix) * C + co : (f * C + co) * HW + pix] = (uint8_t)rintf(v);
+    }
+}
+
 static inline unsigned grid_for(int64_t n, int block)
 {
     int64_t g = (n + block - 1) / block;
@@ -283,6 +313,26 @@ int bsvd_nhwc_to_nchw(const void *src, float *dst, int32_t frames, int32_t C, in
     const int64_t total = (int64_t)frames * H * W;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float *)src, dst, C, H * W, C_pad, total, do_clamp, lo, hi);
+    return (int)hipGetLastError();
+}
+
+int bsvd_u8_to_planar(const uint8_t *src, float *dst, int32_t frames, int32_t C, int32_t H, int32_t W, int32_t src_hwc,
+                      int32_t const_channels, float const_val, void *stream)
+{
+    if (!src || !dst || frames <= 0 || C <= 0 || H <= 0 || W <= 0 || const_channels < 0) { set_error("bsvd_u8_to_planar: bad arguments"); return -3; }
+    const int64_t total = (int64_t)frames * (C + const_channels) * H * W;
+    hipLaunchKernelGGL(u8_to_planar_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
+                       C + const_channels, H * W, src_hwc ? 1 : 0, const_val, total);
+    return (int)hipGetLastError();
+}
+
+int bsvd_planar_to_u8(const float *src, uint8_t *dst, int32_t frames, int32_t C, int32_t H, int32_t W, int32_t dst_hwc,
+                      int32_t reverse_channels, void *stream)
+{
+    if (!src || !dst || frames <= 0 || C <= 0 || H <= 0 || W <= 0) { set_error("bsvd_planar_to_u8: bad arguments"); return -3; }
+    const int64_t total = (int64_t)frames * C * H * W;
+    hipLaunchKernelGGL(planar_to_u8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, C, H * W,
+                       dst_hwc ? 1 : 0, reverse_channels ? 1 : 0, total);
     return (int)hipGetLastError();
 }
 

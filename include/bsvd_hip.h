@@ -137,6 +137,19 @@ int bsvd_nhwc_to_nchw(const void *src, float *dst, int32_t frames, int32_t C, in
                       int32_t C_pad, int32_t dtype, int32_t do_clamp, float lo, float hi, void *stream);
 
 /*
+ * uint8 frame I/O on device (the reference normalises on the host, utils_common.py:184, and rounds
+ * with tensor2img, img_util.py:66,87-90).  u8_to_planar: src uint8 [frames][H][W][C] (src_hwc != 0) or
+ * [frames][C][H][W] -> dst planar fp32 [frames][C + const_channels][H][W] = src/255 with `const_channels` trailing
+ * channels filled with const_val (the constant sigma map of temp_denoise, validation_seq_infer.py:19-21).
+ * planar_to_u8: src planar fp32 [frames][C][H][W] -> clamp to [0,1], x255, round half to even -> uint8, HWC or planar,
+ * optionally with the channel order reversed (RGB -> BGR like tensor2img).
+ */
+int bsvd_u8_to_planar(const uint8_t *src, float *dst, int32_t frames, int32_t C, int32_t H, int32_t W, int32_t src_hwc,
+                      int32_t const_channels, float const_val, void *stream);
+int bsvd_planar_to_u8(const float *src, uint8_t *dst, int32_t frames, int32_t C, int32_t H, int32_t W, int32_t dst_hwc,
+                      int32_t reverse_channels, void *stream);
+
+/*
  * Frame-window sharding: gathers the channel slice [c0, c0+n) of one NHWC frame into
  * a compact [H*W][n] buffer -- the message a rank sends to its temporal neighbour
  * (first frame, c0 = 0 -> the left neighbour's halo_next; last frame, c0 = fold -> the right

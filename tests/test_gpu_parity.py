@@ -382,6 +382,26 @@ def test_half_io_like_profile_py():
     assert maxabs(y.float().cpu().numpy(), want.numpy()) < 2e-2                # fp16 output rounding at |y| ~ 10
 
 
+def test_uint8_frame_io_on_device():
+    """uint8 ingest (+ constant sigma channel) and uint8 output with the reference's clamp + round-half-even."""
+    from bsvd_amd import frame_io
+    from bsvd_amd.evaluation import tensor2img
+    rs = np.random.RandomState(61)
+    u8 = torch.from_numpy(rs.randint(0, 256, (3, 10, 14, 3)).astype(np.uint8))
+    x = frame_io.frames_to_input(u8.to(_dev()), sigma=30 / 255.0)
+    want = torch.cat([torch.from_numpy(np.float32(u8.numpy().transpose(0, 3, 1, 2) / 255.)),
+                      torch.full((3, 1, 10, 14), 30 / 255.0)], dim=1)
+    assert torch.equal(x.cpu(), want)
+    assert torch.equal(frame_io.frames_to_input(u8.permute(0, 3, 1, 2).contiguous().to(_dev()), hwc=False).cpu(), want[:, :3])
+    y = torch.from_numpy(rs.uniform(-0.2, 1.2, (3, 3, 10, 14)).astype(np.float32))
+    y[0, 0, 0, :4] = torch.tensor([0.5 / 255, 1.5 / 255, 2.5 / 255, 254.5 / 255])         # ties -> even
+    got = frame_io.output_to_frames(y.to(_dev()), rgb2bgr=True).cpu().numpy()
+    for f in range(3):
+        assert np.array_equal(got[f], tensor2img(y[f]))                                 # HWC, BGR, rounded like the reference
+    assert np.array_equal(frame_io.output_to_frames(y.to(_dev()), hwc=False).cpu().numpy(),
+                          (y.clamp(0, 1).numpy() * 255.0).round().astype(np.uint8))
+
+
 def test_rejects_bad_arguments():
     from bsvd_amd import _lib
     import ctypes
