@@ -227,6 +227,8 @@ def main():
                 "note": ("algorithmic FLOP over the fp32-MFMA peak (v_mfma_f32_32x32x2_f32)" if precision == "fp32" else
                          "algorithmic FLOP over the dense fp16-MFMA peak; the 3-pass split issues 3 MFMA FLOP per "
                          "algorithmic FLOP, so MFMA-pipe utilisation = 3 x frac"),
+                "mfma_flop_per_algorithmic_flop": 1 if precision == "fp32" else 3,
+                "mfma_pipe_frac": ach * (1 if precision == "fp32" else 3) / peak,
                 "avg_launch_ms": agg[dom]["ms"] / agg[dom]["launches"], "launches": agg[dom]["launches"],
                 "all_conv_kernels": {k: {"ms_per_step": v["ms"] / steps, "tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12,
                                          "launches_per_step": v["launches"] // steps} for k, v in agg.items()},
