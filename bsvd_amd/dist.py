@@ -25,14 +25,16 @@ def shard_range(num_frames, world, rank):
 
 
 class _Pending:
-    def __init__(self, reqs, hp, hn, staged=()):
-        self.reqs, self.hp, self.hn, self.staged = reqs, hp, hn, staged
+    def __init__(self, reqs, hp, hn, staged=(), keep=()):
+        # `keep` pins the packed send slices until finish(): the transfer runs on the backend's own stream
+        self.reqs, self.hp, self.hn, self.staged, self.keep = reqs, hp, hn, staged, keep
 
     def finish(self):
         for req in self.reqs:
             req.wait()          # NCCL/RCCL: orders the current stream after the transfer, no host sync
         for host, dev in self.staged:          # host-staged backends (gloo has no device point-to-point)
             dev.copy_(host, non_blocking=False)
+        self.keep = ()
         return self.hp, self.hn
 
 
@@ -60,7 +62,7 @@ class HaloExchanger:
         if fold == 0 or not (has_left or has_right):
             return _Pending([], None, None)
         H, W = v.shape[1:3]
-        ops, recv_prev, recv_next, staged = [], None, None, []
+        ops, recv_prev, recv_next, staged, keep = [], None, None, [], []
         stage = self.host_staging and v.is_cuda
 
         def wire(t, receiving):
@@ -78,17 +80,19 @@ class HaloExchanger:
             ops += [dist.P2POp(dist.isend, wire(send_last, False), self._peer(self.rank + 1), self.group),
                     dist.P2POp(dist.irecv, wire(recv_next, True), self._peer(self.rank + 1), self.group)]
             self.bytes_sent += send_last.numel() * send_last.element_size()
+            keep.append(send_last)
         if has_left:
             send_first = self.ex.halo_pack(v[0], 0, fold)             # my first frame's [0:fold] -> left's halo_next
             recv_prev = torch.empty((H, W, fold), dtype=v.dtype, device=v.device)
             ops += [dist.P2POp(dist.isend, wire(send_first, False), self._peer(self.rank - 1), self.group),
                     dist.P2POp(dist.irecv, wire(recv_prev, True), self._peer(self.rank - 1), self.group)]
             self.bytes_sent += send_first.numel() * send_first.element_size()
+            keep.append(send_first)
         reqs = dist.batch_isend_irecv(ops)
         self.exchanges += 1
         hp = None if recv_prev is None else Halo(recv_prev, fold, 0)
         hn = None if recv_next is None else Halo(recv_next, fold, 0)
-        return _Pending(reqs, hp, hn, staged)
+        return _Pending(reqs, hp, hn, staged, keep)
 
     def _peer(self, group_rank):
         return group_rank if self.group is None else dist.get_global_rank(self.group, group_rank)
