@@ -1,0 +1,139 @@
+"""Size-independent properties of the HIP path at BASELINE.json's full geometries, where the CPU oracle would take
+minutes: the domain's own invariants stand in for it (the small/medium cases are pinned to the oracle and the reference
+goldens in test_gpu_parity.py / test_gpu_f16x3.py).
+
+* clip schedule == stream schedule, bit for bit (whole-clip formulation == the reference's 16-step-latency pipeline,
+  bsvd_arch.py:485-552);
+* spatial locality: a crop aligned to the two 2x scales gives, beyond the receptive field, exactly the pixels of the
+  full frame (exercises tile edges / ragged tiles at positions the small cases never reach);
+* temporal locality: 16 temporal-fusion convs => frame t sees frames t-16..t+16 only (bsvd_arch.py:554-560 shift_num);
+* frame-window sharding: 8 shards with per-layer halos == the unsharded 80-frame clip, bit for bit.
+"""
+import threading
+
+import pytest
+import torch
+
+from helpers import bsvd_keys
+from seeded import seeded_state
+
+pytestmark = pytest.mark.gpu
+
+RF = 96          # > spatial receptive-field radius of the two DenBlocks (2 x 37 px), multiple of 4
+PRECISIONS = ["f16x3", "fp32"]
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda", 0)
+
+
+def _model(precision, mode="clip"):
+    import bsvd_amd
+    st = seeded_state(bsvd_keys([64, 128, 256], 64, 4, 3, 64), 11)
+    m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, in_ch=4, out_ch=3, norm="none", act="relu6", interm_ch=64,
+                      pretrain_ckpt=None, engine_mode=mode, precision=precision)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
+    return m.to(_dev())
+
+
+def _sigma30_clip(T, H, W, seed):
+    """[T,4,H,W] on the device: uniform 'clean' frames + AWGN sigma=30/255 + constant noise map."""
+    g = torch.Generator(device=_dev()).manual_seed(seed)
+    x = torch.rand((T, 3, H, W), generator=g, device=_dev())
+    x += torch.randn((T, 3, H, W), generator=g, device=_dev()) * (30.0 / 255.0)
+    return torch.cat([x, torch.full((T, 1, H, W), 30.0 / 255.0, device=_dev())], dim=1).contiguous()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_1080p_stream_equals_clip_and_crop_is_local(precision):
+    """BASELINE config 5 (1920x1080 streaming)."""
+    m = _model(precision)
+    x = _sigma30_clip(3, 1080, 1920, 5)
+    y = m.clip_forward(x)
+    assert tuple(y.shape) == (3, 3, 1080, 1920) and bool(torch.isfinite(y).all())
+    m.engine_mode = "stream"
+    assert torch.equal(m(x[None])[0], y)
+    y0, y1, x0, x1 = 256, 256 + 512, 1100, 1920          # crop touching the right image edge, origin multiple of 4
+    yc = m.clip_forward(x[:, :, y0:y1, x0:x1].contiguous())
+    inner = yc[:, :, RF:-RF, RF:]                        # right edge is the image edge in both -> no margin there
+    assert torch.equal(inner, y[:, :, y0 + RF:y1 - RF, x0 + RF:x1])
+    assert not torch.equal(yc[:, :, :4], y[:, :, y0:y0 + 4, x0:x1])   # inside the receptive field the zero pad shows
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_davis_sized_clip_temporal_locality(precision):
+    """BASELINE config 2 geometry (480x856 is not a multiple of the 16-px tile; 85 frames)."""
+    T, H, W = 85, 480, 856
+    m = _model(precision)
+    x = _sigma30_clip(T, H, W, 6)
+    y = m.clip_forward(x)
+    m.engine_mode = "stream"
+    assert torch.equal(m(x[None])[0], y)
+    m.engine_mode = "clip"
+    t0 = 60
+    x2 = x.clone()
+    x2[t0, :3] += 0.25
+    y2 = m.clip_forward(x2)
+    s = m.shift_num
+    assert s == 16
+    assert torch.equal(y2[:t0 - s], y[:t0 - s])                       # frames that cannot see t0 are untouched ...
+    assert torch.equal(y2[t0 + s + 1:], y[t0 + s + 1:])               # ... in both temporal directions
+    for t in (t0 - s // 2, t0, t0 + s // 2):
+        assert not torch.equal(y2[t], y[t])                           # while the frames around it do change
+
+
+class _ThreadHalo:
+    """`world` lock-stepped frame-window 'ranks' on one GPU; same start()/finish() protocol as dist.HaloExchanger."""
+
+    def __init__(self, ex, r, world, boxes, barrier):
+        self.ex, self.r, self.world, self.boxes, self.barrier = ex, r, world, boxes, barrier
+
+    def start(self, sp, v):
+        from bsvd_amd.schedule import Halo
+        fold, r = sp.fold, self.r
+        self.boxes[(r, sp.key)] = (self.ex.halo_pack(v[0], 0, fold), self.ex.halo_pack(v[-1], fold, fold))
+        outer = self
+
+        class Pending:
+            def finish(self):
+                torch.cuda.synchronize()
+                outer.barrier.wait()
+                left = outer.boxes.get((r - 1, sp.key)) if r > 0 else None
+                right = outer.boxes.get((r + 1, sp.key)) if r + 1 < outer.world else None
+                outer.barrier.wait()
+                return (None if left is None else Halo(left[1], fold, 0),
+                        None if right is None else Halo(right[0], fold, 0))
+        return Pending()
+
+    def __call__(self, sp, v):
+        return self.start(sp, v).finish()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_80_frames_in_8_shards_equal_unsharded(precision):
+    """BASELINE config 4 (80-frame 540x960 clip over 8 frame windows), the 8 ranks emulated as threads on one GPU."""
+    from bsvd_amd.dist import shard_range
+    world, T = 8, 80
+    x = _sigma30_clip(T, 540, 960, 7)
+    whole = _model(precision).clip_forward(x)
+    boxes, results, errors = {}, [None] * world, []
+    barrier = threading.Barrier(world)
+
+    def rank(r):
+        try:
+            torch.cuda.set_device(0)
+            m = _model(precision)
+            a, b = shard_range(T, world, r)
+            halo = _ThreadHalo(m._executor(_dev()), r, world, boxes, barrier)
+            results[r] = m.clip_forward(x[a:b], halo)
+            torch.cuda.synchronize()
+        except Exception as e:          # noqa: BLE001 - surface worker failures instead of dead-locking the barrier
+            errors.append(e)
+            barrier.abort()
+
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    assert torch.equal(torch.cat(results), whole)
