@@ -37,11 +37,12 @@ def default_cfg(**over):
 
 
 def _act(x, kind):
-    # get_act_function, bsvd_arch.py:185-192
+    # get_act_function, bsvd_arch.py:185-192; in place like the reference's act_fn(inplace=True) (:126,130,211) --
+    # every call site passes a fresh conv output, and the CPU baseline should not pay allocations the reference avoids
     if kind == "relu6":
-        return torch.clamp(x, 0.0, 6.0)
+        return x.clamp_(0.0, 6.0)
     if kind == "relu":
-        return torch.clamp_min(x, 0.0)
+        return x.clamp_min_(0.0)
     if kind == "none":
         return x
     raise ValueError(kind)
@@ -227,10 +228,9 @@ class _DenBlockStream:
         base = self.s_in.pop_if(o)
         if o is None:
             return None
-        out = o.clone()
-        k = min(3, out.shape[1])
-        out[:, :k] = base[:, :k] - o[:, :k]
-        return out
+        k = min(3, o.shape[1])
+        o[:, :k] = base[:, :k] - o[:, :k]      # in place on the conv output, as bsvd_arch.py:408-414
+        return o
 
 
 class BsvdStream:
