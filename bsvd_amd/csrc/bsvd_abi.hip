@@ -142,6 +142,16 @@ __global__ void halo_pack_kernel(const float *__restrict__ frame, float *__restr
     }
 }
 
+__global__ void halo_unpack_kernel(const float *__restrict__ src, float *__restrict__ frame, int64_t total, int C, int c0,
+                                   int n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / n;
+        const int c = (int)(i - pix * n);
+        frame[pix * C + c0 + c] = src[i];
+    }
+}
+
 // uint8 frame I/O: HWC or planar uint8 -> planar fp32 in [0,1] (+ constant trailing channels, e.g. the
 // sigma map) and back with the reference's clamp + round-half-even (tensor2img, img_util.py:66,87-90)
 __global__ void u8_to_planar_kernel(const uint8_t *__restrict__ src, float *__restrict__ dst, int C, int Cout, int HW,
@@ -345,6 +355,24 @@ int bsvd_halo_pack(const void *frame, void *dst, int32_t HW, int32_t C, int32_t 
     hipLaunchKernelGGL(halo_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float *)frame, (float *)dst, total, C, c0, n);
     return (int)hipGetLastError();
+}
+
+int bsvd_halo_unpack(const void *src, void *frame, int32_t HW, int32_t C, int32_t c0, int32_t n, int32_t dtype,
+                     void *stream)
+{
+    if (dtype != BSVD_F32) { set_error("bsvd_halo_unpack: dtype %d not supported", dtype); return -2; }
+    if (!frame || !src || HW <= 0 || C <= 0 || c0 < 0 || n <= 0 || c0 + n > C) { set_error("bsvd_halo_unpack: bad arguments"); return -3; }
+    const int64_t total = (int64_t)HW * n;
+    hipLaunchKernelGGL(halo_unpack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)src, (float *)frame, total, C, c0, n);
+    return (int)hipGetLastError();
+}
+
+int64_t bsvd_workspace_bytes(const BsvdConvArgs *args)
+{
+    char name[8];
+    const int rc = bsvd_conv3x3_variant(args, name, (int32_t)sizeof(name));   // argument validation only, no launch
+    return rc < 0 ? (int64_t)rc : 0;
 }
 
 }  // extern "C"

@@ -106,6 +106,17 @@ class HipExecutor:
         self.launches += 1
         return out
 
+    def halo_unpack(self, slice_, frame, c0):
+        """scatter a compact [H,W,n] slice into channels [c0,c0+n) of the NHWC frame [H,W,C] (in place)"""
+        H, W, C = frame.shape[-3:]
+        n = slice_.shape[-1]
+        if not (frame.is_contiguous() and slice_.is_contiguous()):
+            raise ValueError("halo_unpack: tensors must be contiguous")
+        rc = self.lib.bsvd_halo_unpack(slice_.data_ptr(), frame.data_ptr(), H * W, C, c0, n, _lib.BSVD_F32, _stream_ptr())
+        _lib.check(rc, "bsvd_halo_unpack")
+        self.launches += 1
+        return frame
+
     def out_shape(self, sp, x):
         """Shape of the NHWC tensor layer ``sp`` produces from NHWC input ``x``."""
         T, H, W, _ = x.shape

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BSVD_ABI_VERSION 3
+#define BSVD_ABI_VERSION 4
 
 /* dtype.  BSVD_F32: exact fp32 (v_mfma_f32_32x32x2_f32).  BSVD_F16X3 ("split16"): every fp32 value v is carried as
  * an fp16 pair hi = fp16(v), lo = fp16(v - hi); a 16-channel chunk of a pixel is stored as [hi x16 | lo x16] in the
@@ -157,6 +157,22 @@ int bsvd_planar_to_u8(const float *src, uint8_t *dst, int32_t frames, int32_t C,
  */
 int bsvd_halo_pack(const void *frame, void *dst, int32_t HW, int32_t C, int32_t c0, int32_t n,
                    int32_t dtype, void *stream);
+
+/*
+ * Inverse of bsvd_halo_pack: scatters a compact [H*W][n] slice into channels [c0, c0+n) of an NHWC frame, for hosts that
+ * keep a materialised neighbour frame (the reference's own `left_fold_2fold` / `center` buffers, bsvd_arch.py:112-113)
+ * instead of handing the slice to bsvd_conv3x3 as halo_prev / halo_next (which reads compact slices in place:
+ * pstride = n, coff = 0).  The other channels of `frame` are left untouched.
+ */
+int bsvd_halo_unpack(const void *src, void *frame, int32_t HW, int32_t C, int32_t c0, int32_t n,
+                     int32_t dtype, void *stream);
+
+/*
+ * Scratch bytes bsvd_conv3x3(args) needs beyond the caller's tensors.  0 for every configuration of this ABI version
+ * (all staging is LDS / registers; the library never allocates) -- exported so a host that sizes its arena from the
+ * library keeps working if a later version wants a workspace.  Validates `args` like bsvd_conv3x3: < 0 = bad argument.
+ */
+int64_t bsvd_workspace_bytes(const BsvdConvArgs *args);
 
 #ifdef __cplusplus
 }

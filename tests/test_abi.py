@@ -101,3 +101,20 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "conv_ref" not in txt, f
+
+
+def test_workspace_bytes_is_zero_and_validates():
+    """bsvd_workspace_bytes: 0 for valid layers (no scratch in this ABI version), the conv's own error code otherwise."""
+    from bsvd_amd import _lib
+    lib = _lib.load()
+    a = _lib.BsvdConvArgs()
+    a.x = a.y = a.w_packed = 16
+    a.frames, a.H, a.W, a.Cin, a.Cout, a.stride = 2, 8, 8, 64, 64, 1
+    assert lib.bsvd_workspace_bytes(ctypes.byref(a)) == 0
+    a.dtype = _lib.BSVD_F16X3
+    assert lib.bsvd_workspace_bytes(ctypes.byref(a)) == 0
+    a.Cin = 12
+    assert lib.bsvd_workspace_bytes(ctypes.byref(a)) == -5
+    assert lib.bsvd_workspace_bytes(None) == -1
+    assert lib.bsvd_halo_unpack(None, None, 4, 16, 0, 8, 0, None) == -3
+    assert lib.bsvd_halo_unpack(16, 16, 4, 16, 12, 8, 0, None) == -3        # c0 + n > C

@@ -402,6 +402,34 @@ def test_uint8_frame_io_on_device():
                           (y.clamp(0, 1).numpy() * 255.0).round().astype(np.uint8))
 
 
+def test_halo_unpack_materialised_neighbours_equal_halo_slices():
+    """bsvd_halo_unpack is the inverse of bsvd_halo_pack, and a temporal-fusion conv fed compact halo slices equals the
+    same conv fed full neighbour frames the slices were unpacked into (the reference's materialised buffers)."""
+    from bsvd_amd.netspec import ConvSpec
+    from bsvd_amd.schedule import Halo
+    net, sp = _one_layer_net(128, 128, 1, True, "relu6", 0)
+    rs = np.random.RandomState(3)
+    st = {"l.weight": (rs.standard_normal((128, 128, 3, 3)) * 0.03).astype(np.float32),
+          "l.bias": rs.standard_normal(128).astype(np.float32) * 0.1}
+    ex = _gpu_exec(net, st)
+    x = torch.from_numpy(rs.standard_normal((3, 10, 19, 128)).astype(np.float32)).to(_dev())
+    fold = sp.fold
+    prev_slice = ex.halo_pack(x[0], fold, fold)
+    next_slice = ex.halo_pack(x[2], 0, fold)
+    assert torch.equal(prev_slice, x[0, :, :, fold:2 * fold]) and torch.equal(next_slice, x[2, :, :, :fold])
+    prev_full = torch.full_like(x[0], 7.0)
+    next_full = torch.full_like(x[0], -7.0)
+    ex.halo_unpack(prev_slice, prev_full, fold)
+    ex.halo_unpack(next_slice, next_full, 0)
+    assert torch.equal(prev_full[:, :, fold:2 * fold], prev_slice) and bool((prev_full[:, :, :fold] == 7.0).all())
+    assert torch.equal(next_full[:, :, :fold], next_slice) and bool((next_full[:, :, fold:] == -7.0).all())
+    mid = x[1:2].contiguous()
+    y_slices = ex.conv(sp, mid, halo_prev=Halo(prev_slice, fold, 0), halo_next=Halo(next_slice, fold, 0))
+    y_full = ex.conv(sp, mid, halo_prev=Halo(prev_full, 128, fold), halo_next=Halo(next_full, 128, 0))
+    y_clip = ex.conv(sp, x)[1:2]
+    assert torch.equal(y_slices, y_full) and torch.equal(y_slices, y_clip)
+
+
 def test_rejects_bad_arguments():
     from bsvd_amd import _lib
     import ctypes
