@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import checkpoint
-from .netspec import make_netspec
+from .netspec import clip_peak_bytes, make_netspec
 from .registry import register_arch
 from .schedule import StreamPipeline, bsvd_clip, planar_ok
 
@@ -137,8 +137,9 @@ class BSVD(_HipNet):
     """Bidirectional-buffer streaming video denoiser on MI355X.
 
     Reference arguments (bsvd_arch.py:446-447) keep their meaning and defaults.  Engine-only keywords:
-      engine_mode : 'clip' (default; layer-major over the whole clip, 32 launches) or 'stream'
-                    (the reference's frame-major pipeline with 16-step latency).  Same function.
+      engine_mode : 'clip' (layer-major over the whole clip, 32 launches), 'stream' (the reference's frame-major
+                    pipeline with 16-step latency, O(1) memory in the clip length) or 'auto' (default: 'clip' when
+                    the clip's activations fit the free HBM, else 'stream').  Same function, bit-identical results.
       clamp       : optional (lo, hi) fused into the exit kernel (callers clamp to [0,1] anyway,
                     validation_seq_infer.py:24).
       precision   : 'fp32' (default; exact fp32 MFMA, bitwise an fmaf chain) or 'f16x3' (split-fp16 3-pass MFMA with
@@ -148,7 +149,7 @@ class BSVD(_HipNet):
 
     def __init__(self, chns=[32, 64, 128], mid_ch=3, shift_input=False, in_ch=4, out_ch=3, norm='bn', act='relu',
                  interm_ch=30, blind=False, pretrain_ckpt='./experiments/pretrained_ckpt/bsvd-64.pth',
-                 engine_mode='clip', clamp=None, precision='fp32'):
+                 engine_mode='auto', clamp=None, precision='fp32'):
         super().__init__()
         if shift_input:
             raise NotImplementedError("shift_input=True (CvBlock input stage) is not used by any BSVD config; "
@@ -156,10 +157,11 @@ class BSVD(_HipNet):
         if norm != 'none':
             raise NotImplementedError("norm=%r: the BSVD configs use norm='none' (options/test/bsvd_c64.yml:90); "
                                       "normalisation layers are not implemented by the MI355X engine" % (norm,))
-        if engine_mode not in ("clip", "stream"):
-            raise ValueError("engine_mode must be 'clip' or 'stream'")
+        if engine_mode not in ("auto", "clip", "stream"):
+            raise ValueError("engine_mode must be 'auto', 'clip' or 'stream'")
         self._init_engine(make_netspec(chns, mid_ch, in_ch, out_ch, act, interm_ch, blind), precision, clamp)
         self.engine_mode = engine_mode
+        self.last_mode = None          # schedule the last forward() actually ran ('clip' | 'stream')
         # Same RNG consumption as the reference constructor (each DenBlock re-initialises itself, then BSVD does it
         # again, bsvd_arch.py:350,453): a seeded run draws the same weights AND leaves the generator in the same state,
         # so the evaluation noise that follows (ValFolderDataset) is the reference's realisation.
@@ -232,11 +234,22 @@ class BSVD(_HipNet):
         input = self._check_input(input, noise_map)
         N, F, C, H, W = input.shape
         frames = input.reshape(N * F, C, H, W)
-        if self.engine_mode == "stream":
+        self.last_mode = self._pick_mode(N * F, H, W)
+        if self.last_mode == "stream":
             out = self.streaming_forward(frames)
         else:
             out = self.clip_forward(frames)
         return out.reshape(N, F, out.shape[1], H, W)
+
+    def _pick_mode(self, frames, H, W):
+        """'auto': the clip schedule keeps up to 4.5 full-resolution 64-channel tensors of the WHOLE clip live (<= 203 GB for 85
+        frames of 1080p -- fits 288 GB; 4K does not); the stream schedule holds a fixed number of frames."""
+        if self.engine_mode != "auto":
+            return self.engine_mode
+        dev = self._device()
+        free, _ = torch.cuda.mem_get_info(dev)
+        free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)     # cached by torch, reusable
+        return "clip" if clip_peak_bytes(self.net, frames, H, W) <= 0.9 * free else "stream"
 
     def count_shift(self):
         return self.net.shift_num

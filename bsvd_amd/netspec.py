@@ -125,6 +125,20 @@ class NetSpec:
         return total
 
 
+def clip_peak_bytes(net, frames, h, w):
+    """Upper bound of the device bytes schedule.bsvd_clip keeps live for a [frames,C,h,w] clip (fp32 words; the
+    split-fp16 mode uses the same 4 bytes per value): per DenBlock the block input (residual base), the inc
+    intermediate and x0 live together at full resolution, later x0 + the decoder tensors; both blocks' peaks do not
+    overlap except for temp1's output = temp2's input.  3.5 x0 covers the live set counted in tests/test_schedule_cpu.py."""
+    unit = 4 * frames * h * w
+    peak = 0
+    for blk in (net.temp1, net.temp2):
+        cin = blk["inc0"].cin_pad if blk["inc0"].cin > 4 else blk["inc0"].cin      # planar 3/4-channel clip input
+        c0 = max(blk["inc0"].cout_pad, blk["inc3"].cout_pad)
+        peak = max(peak, unit * (cin + 3.5 * c0))
+    return int(peak + unit * net.out_ch)
+
+
 def make_netspec(chns=(32, 64, 128), mid_ch=3, in_ch=4, out_ch=3, act="relu", interm_ch=30, blind=False):
     """Defaults are the reference constructor's (bsvd_arch.py:446-447).  ``blind`` follows the WNet
     semantics (only the first stage drops the noise map, wnet_models.py:252-256); the reference's own

@@ -137,3 +137,26 @@ def test_80_frames_in_8_shards_equal_unsharded(precision):
     [t.join() for t in th]
     assert not errors, errors
     assert torch.equal(torch.cat(results), whole)
+
+
+def test_auto_mode_falls_back_to_stream_when_the_clip_does_not_fit(monkeypatch):
+    """engine_mode='auto' (default): clip schedule while its activations fit the free HBM, else the O(1)-memory stream
+    schedule -- same bits either way; the bound that drives the choice covers the measured allocator peak."""
+    from bsvd_amd.netspec import clip_peak_bytes
+    m = _model("f16x3", mode="auto")
+    x = _sigma30_clip(12, 480, 856, 9)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    y = m(x[None])[0]
+    torch.cuda.synchronize()
+    assert m.last_mode == "clip"
+    used = torch.cuda.max_memory_allocated() - base
+    bound = clip_peak_bytes(m.net, 12, 480, 856)
+    print("clip peak %.2f GB, bound %.2f GB" % (used / 1e9, bound / 1e9))
+    assert used <= bound
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a, **k: (1 << 30, 288 << 30))
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda *a, **k: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda *a, **k: 0)
+    y2 = m(x[None])[0]
+    assert m.last_mode == "stream" and torch.equal(y2, y)

@@ -162,3 +162,41 @@ def test_sharded_clip_with_halos_equals_whole_clip():
     [t.join() for t in th]
     y = torch.cat(results).numpy()
     assert maxabs(y, g["out"][0]) < TOL
+
+
+def test_clip_peak_bytes_bound():
+    """engine_mode='auto' sizes the clip schedule from this bound: 85 frames of 1080p fit one MI355X (288 GB), 4K does not."""
+    from bsvd_amd.netspec import make_netspec, clip_peak_bytes
+    net = make_netspec([64, 128, 256], 64, 4, 3, "relu6", 64)
+    b1080 = clip_peak_bytes(net, 85, 1080, 1920)
+    assert 150e9 < b1080 < 0.9 * 288e9
+    assert clip_peak_bytes(net, 85, 2160, 3840) > 288e9
+    assert clip_peak_bytes(net, 10, 540, 960) < 7e9
+    # the bound really is an upper bound of what the schedule keeps live (count NHWC floats through an executor spy)
+    from oracle_exec import OracleExecutor
+    import torch
+    from helpers import bsvd_keys
+    from seeded import seeded_state
+    from bsvd_amd.schedule import bsvd_clip
+    small = make_netspec([32, 64, 128], 32, 4, 3, "relu6", 32)
+    st = seeded_state(bsvd_keys([32, 64, 128], 32, 4, 3, 32), 3)
+    ex = OracleExecutor(st)
+    live, peak = {}, [0]
+    conv = ex.conv
+
+    def spy(sp, x, *a, **k):
+        y = conv(sp, x, *a, **k)
+        live[id(y)] = (y.untyped_storage().nbytes(), __import__("weakref").ref(y))
+        for key in [k_ for k_, (_, r) in live.items() if r() is None]:
+            del live[key]
+        peak[0] = max(peak[0], sum(n for n, _ in live.values()) + x0_bytes)
+        return y
+
+    ex.conv = spy
+    T, H, W = 3, 16, 24
+    x = torch.randn(T, H, W, 16)
+    x[..., 4:] = 0
+    x0_bytes = x.numel() * 4
+    bsvd_clip(ex, small, x)
+    assert 0 < peak[0] <= clip_peak_bytes(small, T, H, W)
+    print('live peak %d B, bound %d B' % (peak[0], clip_peak_bytes(small, T, H, W)))
