@@ -8,5 +8,6 @@ from .arch import BSVD  # noqa: F401
 from .netspec import make_netspec  # noqa: F401
 from .denoise import DenoisingModel, denoise_seq, temp_denoise  # noqa: F401
 from .arch import TSN  # noqa: F401
+from .pipeline import ClipPipeline  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,119 @@
+"""Host <-> device pipelining around the hot path (new component; SURVEY.md 8f-4 "frame I/O on device").
+
+The reference moves every frame to the GPU synchronously on the compute stream (``x.cuda()``,
+/root/reference/Experimental_root/archs/bsvd_arch.py:520) and brings fp32 results back with ``.cpu()`` after a
+``torch.cuda.synchronize()`` (models/validation_seq_infer.py:28, denoising_model.py:187).  Here a sequence of clips
+flows through three HIP streams so PCIe never idles the matrix cores:
+
+    upload stream   : pinned uint8 frames -> HBM                      (4x fewer bytes than the reference's fp32 frames)
+    compute stream  : bsvd_u8_to_planar -> BSVD forward -> bsvd_planar_to_u8   (all kernels of libbsvd_hip.so)
+    download stream : uint8 result -> pinned host buffer
+
+``depth`` slots of pinned staging memory form a ring; slot k is reused once its download has completed.  Results are
+yielded in submission order.
+"""
+import collections
+
+import numpy as np
+import torch
+
+from .frame_io import frames_to_input, output_to_frames
+
+
+class _Slot:
+    def __init__(self):
+        self.pin_in = self.pin_out = None
+        self.dev_in = self.dev_out = None
+        self.shape = None
+        self.uploaded = torch.cuda.Event()
+        self.computed = torch.cuda.Event()
+        self.downloaded = torch.cuda.Event()
+        self.ticket = None          # the in-flight clip occupying this slot
+
+
+class _Ticket:
+    """One submitted clip: owns its slot until the download has been copied out of the pinned buffer."""
+
+    def __init__(self, slot):
+        self.slot, self.result = slot, None
+
+    def finish(self):
+        if self.slot is not None:
+            self.slot.downloaded.synchronize()
+            self.result = self.slot.pin_out.numpy().copy()
+            self.slot.ticket = None
+            self.slot = None
+        return self.result
+
+
+class ClipPipeline:
+    """model: a bsvd_amd.BSVD on a HIP device.  sigma: noise std in [0,1] units for the constant noise map (None for a
+    blind model).  depth >= 2 overlaps the transfers of one clip with the forward of another."""
+
+    def __init__(self, model, sigma=None, depth=2):
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.model, self.sigma = model, sigma
+        self.device = model._device()
+        if self.device.type != "cuda":
+            raise RuntimeError("ClipPipeline needs the model on a HIP device (model.cuda())")
+        with torch.cuda.device(self.device):
+            self.up, self.comp, self.down = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream())
+            self.slots = [_Slot() for _ in range(depth)]
+        self.pending = collections.deque()
+        self.count = 0
+
+    # ------------------------------------------------------------------------------------------------
+    def submit(self, frames_u8):
+        """frames_u8: numpy uint8 [T,H,W,3] (RGB).  Enqueues upload + forward + download; returns immediately unless
+        the ring is full (then it first drains the oldest clip into its result)."""
+        frames_u8 = np.ascontiguousarray(frames_u8)
+        if frames_u8.dtype != np.uint8 or frames_u8.ndim != 4 or frames_u8.shape[-1] != 3:
+            raise ValueError("expected uint8 frames [T,H,W,3]")
+        if frames_u8.shape[1] % 4 or frames_u8.shape[2] % 4:
+            raise ValueError("H and W must be multiples of 4 (pad first: denoise.pad_to_multiple_of_4)")
+        slot = self.slots[self.count % len(self.slots)]
+        self.count += 1
+        if slot.ticket is not None:
+            slot.ticket.finish()               # ring full: the oldest clip's result leaves the pinned buffer first
+        with torch.cuda.device(self.device):
+            if slot.shape != frames_u8.shape:
+                slot.shape = frames_u8.shape
+                slot.pin_in = torch.empty(frames_u8.shape, dtype=torch.uint8).pin_memory()
+                slot.pin_out = torch.empty(frames_u8.shape, dtype=torch.uint8).pin_memory()
+                slot.dev_in = torch.empty(frames_u8.shape, dtype=torch.uint8, device=self.device)
+            slot.pin_in.numpy()[...] = frames_u8
+            with torch.cuda.stream(self.up):
+                slot.dev_in.copy_(slot.pin_in, non_blocking=True)
+                slot.uploaded.record()
+            with torch.cuda.stream(self.comp):
+                self.comp.wait_event(slot.uploaded)
+                x = frames_to_input(slot.dev_in, self.sigma)
+                T, _, H, W = x.shape
+                if self.model._pick_mode(T, H, W) == "clip":
+                    y = self.model.clip_forward(x)
+                else:
+                    y = self.model.streaming_forward(x)
+                slot.dev_out = output_to_frames(y.float())          # held by the slot until its download completed
+                slot.computed.record()
+            with torch.cuda.stream(self.down):
+                self.down.wait_event(slot.computed)
+                slot.pin_out.copy_(slot.dev_out, non_blocking=True)
+                slot.downloaded.record()
+        slot.ticket = _Ticket(slot)
+        self.pending.append(slot.ticket)
+        return slot.ticket
+
+    def results(self):
+        """Drains every clip submitted so far, in submission order."""
+        while self.pending:
+            yield self.pending.popleft().finish()
+
+    def run(self, clips):
+        """clips: iterable of uint8 [T,H,W,3] arrays -> generator of denoised uint8 [T,H,W,3] arrays, in order, with up
+        to ``depth`` clips in flight."""
+        for clip in clips:
+            if len(self.pending) == len(self.slots):
+                yield self.pending.popleft().finish()
+            self.submit(clip)
+        yield from self.results()

@@ -108,3 +108,34 @@ def test_psnr_parity_proxy_within_0p02_db(precision):
                 - E.calculate_psnr_float(want[f], clean[f], 2))
         assert abs(d_u8) < 0.02 and abs(d_fl) < 0.02, (precision, f, d_u8, d_fl)
         assert abs(d_fl) < 1e-3          # in fact three orders of magnitude inside the budget
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_clip_pipeline_overlapped_transfers_match_the_direct_path(depth):
+    """bsvd_amd.pipeline.ClipPipeline (uint8 upload / forward / uint8 download on three streams, pinned ring of
+    `depth` slots) returns, in order, exactly the bytes of the synchronous path."""
+    import bsvd_amd
+    from bsvd_amd.frame_io import frames_to_input, output_to_frames
+    from bsvd_amd.pipeline import ClipPipeline
+    rs = np.random.RandomState(21)
+    dev = torch.device("cuda", 0)
+    st = seeded_state(bsvd_keys([64, 128, 256], 64, 4, 3, 64), 11)
+    m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, in_ch=4, out_ch=3, norm="none", act="relu6", interm_ch=64,
+                      pretrain_ckpt=None, precision="f16x3")
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
+    m = m.to(dev)
+    clips = [rs.randint(0, 256, (3 + (i % 2), 64, 96, 3)).astype(np.uint8) for i in range(5)]   # shapes alternate
+    sigma = 30 / 255.0
+    want = [output_to_frames(m.clip_forward(frames_to_input(torch.from_numpy(c).to(dev), sigma))).cpu().numpy()
+            for c in clips]
+    pipe = ClipPipeline(m, sigma=sigma, depth=depth)
+    got = list(pipe.run(iter(clips)))
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g.dtype == np.uint8 and g.shape == w.shape and np.array_equal(g, w)
+    tickets = [pipe.submit(c) for c in clips[:4]]          # more submissions than slots: older results are retained
+    again = list(pipe.results())
+    assert all(np.array_equal(a, w) for a, w in zip(again, want[:4])) and len(again) == 4
+    assert all(np.array_equal(t.finish(), w) for t, w in zip(tickets, want[:4]))
+    with pytest.raises(ValueError):
+        pipe.submit(np.zeros((2, 30, 50, 3), np.uint8))     # not a multiple of 4
