@@ -124,6 +124,9 @@ class _HipNet(nn.Module):
         if noise_map is not None:
             input = torch.cat([input, noise_map], dim=2)
         C, H, W = input.shape[-3:]
+        if input.numel() == 0:
+            raise ValueError("empty clip %s (the reference fails on it too: torch.cat of no frames, "
+                             "bsvd_arch.py:552)" % (tuple(input.shape),))
         if C != self.net.net_in_ch:
             raise ValueError("expected %d input channels (incl. noise map), got %d" % (self.net.net_in_ch, C))
         if H % 4 or W % 4:

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "bsvd_hip.h"
 
 namespace bsvd {
@@ -28,6 +29,22 @@ struct ConvParams {
 };
 
 void set_error(const char *fmt, ...);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember, per device, the largest
+// size already granted for one kernel (`granted` = a zero-initialised static array of MAX_DEVICES atomics owned by
+// the launcher).  Thread-safe; a lost race only repeats an idempotent call.
+constexpr int MAX_DEVICES = 64;
+inline hipError_t ensure_dynamic_lds(const void *fn, int bytes, std::atomic<int> *granted)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= MAX_DEVICES) dev = 0;
+    if (bytes <= granted[dev].load(std::memory_order_relaxed)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) granted[dev].store(bytes, std::memory_order_relaxed);
+    return e;
+}
 
 // conv3x3_mfma.hip
 // name != nullptr: dry run, only writes the kernel instantiation that would be launched

@@ -272,12 +272,11 @@ int launch_tail_f32(const ConvParams &p, int cout_real, int do_clamp, float lo, 
     if (ncb > TailCfg::MAX_CHUNKS) { set_error("bsvd_conv3x3: planar-output layer supports Cin <= %d", TailCfg::MAX_CHUNKS * 16); return -15; }
     const int cc = cout_real == 3 ? 3 : 4;
     const int lds = TailCfg::lds_bytes(ncb, cc);
-    static int lds_attr[2] = {0, 0};       // largest dynamic-LDS size already granted per instantiation
+    static std::atomic<int> granted[2][MAX_DEVICES];
     const void *fn = cc == 3 ? reinterpret_cast<const void *>(&tail_kernel<3>) : reinterpret_cast<const void *>(&tail_kernel<4>);
-    if (lds > 64 * 1024 && lds > lds_attr[cc - 3]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (lds > 64 * 1024) {
+        hipError_t e = ensure_dynamic_lds(fn, lds, granted[cc - 3]);
         if (e != hipSuccess) return (int)e;
-        lds_attr[cc - 3] = lds;
     }
     if (cc == 3)
         hipLaunchKernelGGL(tail_kernel<3>, dim3((unsigned)nblk), dim3(256), lds, stream, p, cout_real, do_clamp, lo, hi);

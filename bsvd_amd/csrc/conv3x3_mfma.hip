@@ -573,13 +573,9 @@ static int launch_cfg(const ConvParams &pin, hipStream_t stream, char *name = nu
     p.nct = (p.Cout + C::BN - 1) / C::BN;
     const int64_t nblk = (int64_t)p.frames * p.nty * p.ntx * p.nct;
     if (nblk <= 0 || nblk > 0x7fffffff) { set_error("bsvd_conv3x3: grid of %lld workgroups", (long long)nblk); return -1; }
-    static bool attr_done = false;   // benign race: the call is idempotent
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_kernel<C, FAST, PREC>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static std::atomic<int> granted[MAX_DEVICES];
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv3x3_kernel<C, FAST, PREC>), C::LDS_BYTES, granted);
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((conv3x3_kernel<C, FAST, PREC>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, stream, p);
     return (int)hipGetLastError();
 }

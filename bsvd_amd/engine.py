@@ -136,6 +136,11 @@ class HipExecutor:
         a = _lib.BsvdConvArgs()
         if not x.is_contiguous():
             raise ValueError("%s: input must be contiguous" % sp.key)
+        for name, t in (("input", x), ("extra", extra), ("halo_prev", halo_prev and halo_prev.t),
+                        ("halo_next", halo_next and halo_next.t), ("out", out)):
+            if t is not None and (not t.is_cuda or t.dtype != torch.float32 or t.device != x.device):
+                raise ValueError("%s: %s must be a float32 tensor on %s (got %s on %s)"
+                                 % (sp.key, name, x.device, t.dtype, t.device))
         if x_planar:
             T, C, H, W = x.shape
             if C != sp.cin or sp.cin_pad != 16 or sp.stride != 1 or sp.tsm:

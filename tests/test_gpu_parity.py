@@ -441,3 +441,17 @@ def test_rejects_bad_arguments():
     m = bsvd_amd.BSVD(norm="none", pretrain_ckpt=None).to(_dev())
     with pytest.raises(ValueError):
         m(torch.zeros(1, 2, 4, 18, 26, device=_dev()))     # not a multiple of 4 (reference fails at the skip add)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 0, 4, 16, 16, device=_dev()))     # empty clip (reference: torch.cat of nothing)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 2, 5, 16, 16, device=_dev()))     # wrong channel count
+    # the executor refuses host tensors / wrong dtypes instead of handing their pointers to a kernel
+    net, sp = _one_layer_net(64, 64, 1, False, "relu6", 0)
+    rs = np.random.RandomState(0)
+    ex = _gpu_exec(net, {"l.weight": rs.standard_normal((64, 64, 3, 3)).astype(np.float32), "l.bias": np.zeros(64, np.float32)})
+    with pytest.raises(ValueError):
+        ex.conv(sp, torch.zeros(1, 8, 8, 64))
+    with pytest.raises(ValueError):
+        ex.conv(sp, torch.zeros(1, 8, 8, 64, device=_dev(), dtype=torch.float16))
+    with pytest.raises(ValueError):
+        ex.conv(sp, torch.zeros(1, 8, 8, 64, device=_dev()), out=torch.zeros(1, 8, 8, 64))
