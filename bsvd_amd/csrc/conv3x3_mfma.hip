@@ -179,8 +179,14 @@ struct ChunkSrc {          // wave-uniform description of one 16-channel chunk's
 };
 
 // ------------------------------------------------------------------------------------------------------
+#ifndef BSVD_TUNE_S2F32_OCC
+#define BSVD_TUNE_S2F32_OCC 2      // waves/SIMD the exact-fp32 stride-2 kernel is compiled for (3 = 168 VGPRs + a 20-B spill: 2.3 % slower)
+#endif
+template <class C, int PREC>
+constexpr int occ_of() { return (C::STRIDE == 2 && PREC == 0 && C::OCC > BSVD_TUNE_S2F32_OCC) ? BSVD_TUNE_S2F32_OCC : C::OCC; }
+
 template <class C, bool FAST, int PREC>
-__global__ __launch_bounds__(256, C::OCC) void conv3x3_kernel(const ConvParams p)
+__global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *const patch_buf = smem;                              // 2 x PATCH_FLOATS
