@@ -179,6 +179,9 @@ struct ChunkSrc {          // wave-uniform description of one 16-channel chunk's
 };
 
 // ------------------------------------------------------------------------------------------------------
+#ifndef BSVD_TUNE_FAT_MIN_WGS
+#define BSVD_TUNE_FAT_MIN_WGS 1024  // smallest grid (in 256-px x 128-ch workgroups) that takes the fat split tile
+#endif
 #ifndef BSVD_TUNE_S2F32_OCC
 #define BSVD_TUNE_S2F32_OCC 2      // waves/SIMD the exact-fp32 stride-2 kernel is compiled for (3 = 168 VGPRs + a 20-B spill: 2.3 % slower)
 #endif
@@ -614,7 +617,7 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
         // (streaming mode: one frame per launch) keep the 64x64 tiles at 3 workgroups per CU.
         const int64_t fat_wide = (int64_t)p.frames * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16) * ((p.Cout + 127) / 128);
         if (p.Cout > 64)
-            return fat_wide >= 1024 ? launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len)
+            return fat_wide >= BSVD_TUNE_FAT_MIN_WGS ? launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len)
                                     : launch_cfg<ConvCfg<2, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
         return launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1>(p, stream, name, name_len);   // (512-px fat tiles were tried: 9.6 vs 6.8 ms)
     }
