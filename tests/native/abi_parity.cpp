@@ -1,0 +1,183 @@
+// Torch-free consumer of the C ABI (include/bsvd_hip.h): what a non-Python host would write.
+// TEST INFRASTRUCTURE: links libbsvd_hip.so (the product) and oracle/conv_ref.c (the plain-C double-accumulating
+// checker) and compares them layer by layer -- device memory comes straight from the HIP runtime, no PyTorch anywhere.
+//
+//   case 1  temporal-fusion conv 128->128 (ShiftConv + ReLU6, bsvd_arch.py:42-50,133-141) over a 3-frame clip with both
+//           neighbour-shard halos, exact-fp32 mode
+//   case 2  stride-2 conv 64->128 + ReLU6 (DownBlock, :238)
+//   case 3  conv 128->256 + PixelShuffle(2) + skip add (UpBlock :265-266, none_add :402)
+//   case 4  3-layer chain in split-fp16 mode: planar 4-channel input -> head 4->64 -> conv 64->64 (BSVD_F16X3) -> tail
+//           64->3 with residual + clamp, planar output  (InputCvBlock / OutputCvBlock + none_minus :408-414)
+//
+// Built by __graft_entry__.build() (tests/native/Makefile); run by tests/test_gpu_native.py on the MI355X.
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "bsvd_hip.h"
+
+extern "C" int oracle_conv3x3(const float *cur, const float *prev_sl, const float *next_sl, int fold, const float *w,
+                              const float *bias, int Cin, int Cout, int H, int W, int stride, int act, int epilogue,
+                              const float *extra, float *out);
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+#define ABI_OK(x) do { int r_ = (x); if (r_ != 0) { printf("ABI error %d (%s) at %s:%d\n", r_, bsvd_last_error(), __FILE__, __LINE__); exit(3); } } while (0)
+
+static uint32_t rng_state = 12345u;
+static float frand() {                       // uniform in [-1, 1)
+    rng_state = rng_state * 1664525u + 1013904223u;
+    return (float)((rng_state >> 8) & 0xffffff) / 8388608.0f - 1.0f;
+}
+static std::vector<float> randv(size_t n, float scale) { std::vector<float> v(n); for (auto &x : v) x = frand() * scale; return v; }
+
+template <class T> static T *dev(const std::vector<T> &h) {
+    T *d = nullptr; HIP_OK(hipMalloc((void **)&d, h.size() * sizeof(T) + 16));
+    HIP_OK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); return d;
+}
+static float *dev_zeros(size_t n) { float *d = nullptr; HIP_OK(hipMalloc((void **)&d, n * 4 + 16)); HIP_OK(hipMemset(d, 0, n * 4)); return d; }
+static std::vector<float> host(const float *d, size_t n) { std::vector<float> h(n); HIP_OK(hipMemcpy(h.data(), d, n * 4, hipMemcpyDeviceToHost)); return h; }
+
+// NCHW frame [C][H][W] -> NHWC [H][W][Cp] (zero-padded channels) and back
+static std::vector<float> to_nhwc(const std::vector<float> &x, int T, int C, int H, int W, int Cp) {
+    std::vector<float> y((size_t)T * H * W * Cp, 0.f);
+    for (int t = 0; t < T; ++t) for (int c = 0; c < C; ++c) for (int p = 0; p < H * W; ++p)
+        y[((size_t)t * H * W + p) * Cp + c] = x[((size_t)t * C + c) * H * W + p];
+    return y;
+}
+static std::vector<float> to_nchw(const std::vector<float> &y, int T, int C, int H, int W, int Cp) {
+    std::vector<float> x((size_t)T * C * H * W);
+    for (int t = 0; t < T; ++t) for (int c = 0; c < C; ++c) for (int p = 0; p < H * W; ++p)
+        x[((size_t)t * C + c) * H * W + p] = y[((size_t)t * H * W + p) * Cp + c];
+    return x;
+}
+static double maxabs(const std::vector<float> &a, const std::vector<float> &b) {
+    double m = 0; if (a.size() != b.size()) return 1e30;
+    for (size_t i = 0; i < a.size(); ++i) { double d = fabs((double)a[i] - (double)b[i]); if (!(d <= m)) m = d; }
+    return m;
+}
+
+struct Packed { float *w, *b; };
+static Packed pack(const std::vector<float> &w, const std::vector<float> &b, int Cin, int Cout, int Cinp, int Coutp, int ps, int dtype) {
+    float *dw = dev(w), *db = dev(b);
+    Packed p; p.w = dev_zeros((size_t)bsvd_packed_weight_elems(Cinp, Coutp)); p.b = dev_zeros(Coutp);
+    ABI_OK(bsvd_pack_weights(dw, db, Cin, Cout, Cinp, Coutp, ps, dtype, p.w, p.b, nullptr));
+    HIP_OK(hipDeviceSynchronize()); HIP_OK(hipFree(dw)); HIP_OK(hipFree(db));
+    return p;
+}
+
+static int failures = 0;
+static void report(const char *name, double err, double tol) {
+    printf("%-72s max-abs %.3e (tol %.0e) %s\n", name, err, tol, err < tol ? "ok" : "FAIL");
+    if (!(err < tol)) ++failures;
+}
+
+static void case_tsm() {
+    const int T = 3, C = 128, H = 10, W = 19, fold = C / 8;
+    auto x = randv((size_t)T * C * H * W, 1.f), w = randv((size_t)C * C * 9, 0.04f), b = randv(C, 0.1f);
+    auto prevf = randv((size_t)C * H * W, 1.f), nextf = randv((size_t)C * H * W, 1.f);      // neighbour shards' boundary frames
+    float *dx = dev(to_nhwc(x, T, C, H, W, C)), *dp = dev(to_nhwc(prevf, 1, C, H, W, C)), *dn = dev(to_nhwc(nextf, 1, C, H, W, C));
+    float *dy = dev_zeros((size_t)T * H * W * C);
+    Packed pk = pack(w, b, C, C, C, C, 0, BSVD_F32);
+    BsvdConvArgs a; memset(&a, 0, sizeof(a));
+    a.x = dx; a.x_frame_stride = (int64_t)H * W * C; a.fold = fold;
+    a.halo_prev = dp; a.halo_prev_pstride = C; a.halo_prev_coff = fold;      // full NHWC frame: channels [fold, 2fold)
+    a.halo_next = dn; a.halo_next_pstride = C; a.halo_next_coff = 0;         //                 channels [0, fold)
+    a.w_packed = pk.w; a.bias_packed = pk.b; a.y = dy; a.y_frame_stride = (int64_t)H * W * C;
+    a.frames = T; a.H = H; a.W = W; a.Cin = C; a.Cout = C; a.stride = 1; a.act = BSVD_ACT_RELU6; a.epilogue = BSVD_EPI_PLAIN; a.dtype = BSVD_F32;
+    if (bsvd_workspace_bytes(&a) != 0) { printf("workspace bytes != 0\n"); ++failures; }
+    ABI_OK(bsvd_conv3x3(&a, nullptr)); HIP_OK(hipDeviceSynchronize());
+    auto got = to_nchw(host(dy, (size_t)T * H * W * C), T, C, H, W, C);
+    std::vector<float> want((size_t)T * C * H * W);
+    const size_t fr = (size_t)C * H * W, pl = (size_t)H * W;
+    for (int t = 0; t < T; ++t) {
+        const float *pv = (t == 0 ? prevf.data() : x.data() + (t - 1) * fr) + fold * pl;     // channels fold..2fold-1
+        const float *nx = (t == T - 1 ? nextf.data() : x.data() + (t + 1) * fr);              // channels 0..fold-1
+        if (oracle_conv3x3(x.data() + t * fr, pv, nx, fold, w.data(), b.data(), C, C, H, W, 1, 2, 0, nullptr, want.data() + t * fr)) exit(4);
+    }
+    report("temporal-fusion conv 128->128, 3 frames + both halos, fp32", maxabs(got, want), 1e-4);
+}
+
+static void case_stride2() {
+    const int T = 2, Ci = 64, Co = 128, H = 21, W = 36, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    auto x = randv((size_t)T * Ci * H * W, 1.f), w = randv((size_t)Co * Ci * 9, 0.05f), b = randv(Co, 0.1f);
+    float *dx = dev(to_nhwc(x, T, Ci, H, W, Ci)), *dy = dev_zeros((size_t)T * Ho * Wo * Co);
+    Packed pk = pack(w, b, Ci, Co, Ci, Co, 0, BSVD_F32);
+    BsvdConvArgs a; memset(&a, 0, sizeof(a));
+    a.x = dx; a.x_frame_stride = (int64_t)H * W * Ci; a.w_packed = pk.w; a.bias_packed = pk.b; a.y = dy; a.y_frame_stride = (int64_t)Ho * Wo * Co;
+    a.frames = T; a.H = H; a.W = W; a.Cin = Ci; a.Cout = Co; a.stride = 2; a.act = BSVD_ACT_RELU6; a.dtype = BSVD_F32;
+    ABI_OK(bsvd_conv3x3(&a, nullptr)); HIP_OK(hipDeviceSynchronize());
+    auto got = to_nchw(host(dy, (size_t)T * Ho * Wo * Co), T, Co, Ho, Wo, Co);
+    std::vector<float> want((size_t)T * Co * Ho * Wo);
+    for (int t = 0; t < T; ++t)
+        if (oracle_conv3x3(x.data() + (size_t)t * Ci * H * W, nullptr, nullptr, 0, w.data(), b.data(), Ci, Co, H, W, 2, 2, 0, nullptr, want.data() + (size_t)t * Co * Ho * Wo)) exit(4);
+    report("stride-2 conv 64->128 on 21x36 (odd height), fp32", maxabs(got, want), 1e-4);
+}
+
+static void case_pixel_shuffle() {
+    const int T = 2, Ci = 128, Co = 256, Cq = Co / 4, H = 9, W = 13;
+    auto x = randv((size_t)T * Ci * H * W, 1.f), w = randv((size_t)Co * Ci * 9, 0.04f), b = randv(Co, 0.1f);
+    auto skip = randv((size_t)T * Cq * 4 * H * W, 1.f);                                       // [T][Cq][2H][2W]
+    float *dx = dev(to_nhwc(x, T, Ci, H, W, Ci)), *ds = dev(to_nhwc(skip, T, Cq, 2 * H, 2 * W, Cq)), *dy = dev_zeros((size_t)T * 4 * H * W * Cq);
+    Packed pk = pack(w, b, Ci, Co, Ci, Co, 1, BSVD_F32);
+    BsvdConvArgs a; memset(&a, 0, sizeof(a));
+    a.x = dx; a.x_frame_stride = (int64_t)H * W * Ci; a.w_packed = pk.w; a.bias_packed = pk.b;
+    a.extra = ds; a.extra_frame_stride = (int64_t)4 * H * W * Cq; a.extra_pstride = Cq; a.extra_cstride = 1;
+    a.y = dy; a.y_frame_stride = (int64_t)4 * H * W * Cq;
+    a.frames = T; a.H = H; a.W = W; a.Cin = Ci; a.Cout = Co; a.stride = 1; a.act = BSVD_ACT_NONE; a.epilogue = BSVD_EPI_PS_ADD; a.dtype = BSVD_F32;
+    ABI_OK(bsvd_conv3x3(&a, nullptr)); HIP_OK(hipDeviceSynchronize());
+    auto got = to_nchw(host(dy, (size_t)T * 4 * H * W * Cq), T, Cq, 2 * H, 2 * W, Cq);
+    std::vector<float> want((size_t)T * Cq * 4 * H * W);
+    for (int t = 0; t < T; ++t)
+        if (oracle_conv3x3(x.data() + (size_t)t * Ci * H * W, nullptr, nullptr, 0, w.data(), b.data(), Ci, Co, H, W, 1, 0, 1,
+                           skip.data() + (size_t)t * Cq * 4 * H * W, want.data() + (size_t)t * Cq * 4 * H * W)) exit(4);
+    report("conv 128->256 + PixelShuffle(2) + skip add, fp32", maxabs(got, want), 1e-4);
+}
+
+static void case_split_chain() {
+    const int T = 2, H = 24, W = 40, C = 64;
+    auto x = randv((size_t)T * 4 * H * W, 1.f);                                               // planar [T][4][H][W]
+    auto w1 = randv((size_t)C * 4 * 9, 0.3f), b1 = randv(C, 0.1f);
+    auto w2 = randv((size_t)C * C * 9, 0.06f), b2 = randv(C, 0.1f);
+    auto w3 = randv((size_t)3 * C * 9, 0.06f), b3 = randv(3, 0.1f);
+    float *dx = dev(x), *d1 = dev_zeros((size_t)T * H * W * C), *d2 = dev_zeros((size_t)T * H * W * C), *dy = dev_zeros((size_t)T * 3 * H * W);
+    Packed p1 = pack(w1, b1, 4, C, 16, C, 0, BSVD_F32);          // edge layers keep fp32 packs (VALU kernels)
+    Packed p2 = pack(w2, b2, C, C, C, C, 0, BSVD_F16X3);
+    Packed p3 = pack(w3, b3, C, 3, C, 16, 0, BSVD_F32);
+    BsvdConvArgs a; memset(&a, 0, sizeof(a));
+    a.x = dx; a.x_frame_stride = (int64_t)4 * H * W; a.x_planar_ch = 4; a.w_packed = p1.w; a.bias_packed = p1.b;
+    a.y = d1; a.y_frame_stride = (int64_t)H * W * C; a.frames = T; a.H = H; a.W = W; a.Cin = 16; a.Cout = C; a.stride = 1;
+    a.act = BSVD_ACT_RELU6; a.dtype = BSVD_F16X3;
+    ABI_OK(bsvd_conv3x3(&a, nullptr));
+    memset(&a, 0, sizeof(a));
+    a.x = d1; a.x_frame_stride = (int64_t)H * W * C; a.w_packed = p2.w; a.bias_packed = p2.b; a.y = d2; a.y_frame_stride = (int64_t)H * W * C;
+    a.frames = T; a.H = H; a.W = W; a.Cin = C; a.Cout = C; a.stride = 1; a.act = BSVD_ACT_RELU6; a.dtype = BSVD_F16X3;
+    ABI_OK(bsvd_conv3x3(&a, nullptr));
+    memset(&a, 0, sizeof(a));
+    a.x = d2; a.x_frame_stride = (int64_t)H * W * C; a.w_packed = p3.w; a.bias_packed = p3.b; a.y = dy; a.y_frame_stride = (int64_t)3 * H * W;
+    a.extra = dx; a.extra_frame_stride = (int64_t)4 * H * W; a.extra_pstride = 1; a.extra_cstride = H * W; a.resid_ch = 3;   // planar base
+    a.frames = T; a.H = H; a.W = W; a.Cin = C; a.Cout = 16; a.stride = 1; a.act = BSVD_ACT_NONE; a.epilogue = BSVD_EPI_RESID;
+    a.dtype = BSVD_F16X3; a.y_planar_ch = 3; a.y_clamp = 1; a.y_lo = -0.5f; a.y_hi = 0.75f;
+    ABI_OK(bsvd_conv3x3(&a, nullptr)); HIP_OK(hipDeviceSynchronize());
+    auto got = host(dy, (size_t)T * 3 * H * W);
+    std::vector<float> want((size_t)T * 3 * H * W), t1((size_t)C * H * W), t2((size_t)C * H * W);
+    for (int t = 0; t < T; ++t) {
+        const float *xf = x.data() + (size_t)t * 4 * H * W;
+        if (oracle_conv3x3(xf, nullptr, nullptr, 0, w1.data(), b1.data(), 4, C, H, W, 1, 2, 0, nullptr, t1.data())) exit(4);
+        if (oracle_conv3x3(t1.data(), nullptr, nullptr, 0, w2.data(), b2.data(), C, C, H, W, 1, 2, 0, nullptr, t2.data())) exit(4);
+        if (oracle_conv3x3(t2.data(), nullptr, nullptr, 0, w3.data(), b3.data(), C, 3, H, W, 1, 0, 2, xf, want.data() + (size_t)t * 3 * H * W)) exit(4);
+    }
+    for (auto &v : want) v = fminf(fmaxf(v, -0.5f), 0.75f);
+    report("split-fp16 chain: planar in -> 4->64 -> 64->64 (f16x3) -> 64->3 resid+clamp", maxabs(got, want), 1e-3);
+}
+
+int main() {
+    if (bsvd_abi_version() != BSVD_ABI_VERSION || bsvd_conv_args_size() != (int)sizeof(BsvdConvArgs)) { printf("ABI mismatch\n"); return 1; }
+    int n = 0; HIP_OK(hipGetDeviceCount(&n)); if (n < 1) { printf("no HIP device\n"); return 1; }
+    HIP_OK(hipSetDevice(0));
+    case_tsm(); case_stride2(); case_pixel_shuffle(); case_split_chain();
+    printf(failures ? "abi_parity: %d FAILED\n" : "abi_parity: all cases ok\n", failures);
+    return failures ? 1 : 0;
+}
