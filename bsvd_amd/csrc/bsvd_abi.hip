@@ -86,7 +86,7 @@ __global__ void pack_weights_split_kernel(const float *__restrict__ w, const flo
         }
         const float v = ok ? w[((int64_t)n * Cin + c) * 9 + tap] : 0.f;
         const _Float16 hi = (_Float16)v;
-        wp[i] = part ? (_Float16)(v - (float)hi) : hi;
+        wp[i] = part ? lo_keep((_Float16)(v - (float)hi)) : hi;
         if (bp && i < Cout_pad) {
             int nb = (int)i;
             bool okb;

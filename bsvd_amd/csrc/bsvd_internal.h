@@ -30,6 +30,24 @@ struct ConvParams {
 
 void set_error(const char *fmt, ...);
 
+// Experiment knob: keep only the top BSVD_TUNE_LO_BITS mantissa bits of the `lo` half of a split16 pair (10 = all;
+// -1 = lo := 0).  Probes how much of the power-limited split kernel's energy is operand toggling.
+#ifndef BSVD_TUNE_LO_BITS
+#define BSVD_TUNE_LO_BITS 10
+#endif
+__host__ __device__ inline _Float16 lo_keep(_Float16 lo)
+{
+#if BSVD_TUNE_LO_BITS >= 10
+    return lo;
+#elif BSVD_TUNE_LO_BITS < 0
+    return (_Float16)0.f;
+#else
+    unsigned short u = __builtin_bit_cast(unsigned short, lo);
+    u &= (unsigned short)~((1u << (10 - BSVD_TUNE_LO_BITS)) - 1u);
+    return __builtin_bit_cast(_Float16, u);
+#endif
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember, per device, the largest
 // size already granted for one kernel (`granted` = a zero-initialised static array of MAX_DEVICES atomics owned by
 // the launcher).  Thread-safe; a lost race only repeats an idempotent call.

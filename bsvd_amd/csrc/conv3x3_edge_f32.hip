@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void head_kernel(const ConvParams p)
                 const float v = fminf(fmaxf(edge_act(acc[j], p.act), -65504.f), 65504.f);   // saturate, never inf/NaN pairs
                 const _Float16 h = (_Float16)v;
                 hi[j >> 3][j & 7] = h;
-                lo[j >> 3][j & 7] = (_Float16)(v - (float)h);
+                lo[j >> 3][j & 7] = lo_keep((_Float16)(v - (float)h));
             }
             o[0] = __builtin_bit_cast(f32x4, hi[0]); o[1] = __builtin_bit_cast(f32x4, hi[1]);
             o[2] = __builtin_bit_cast(f32x4, lo[0]); o[3] = __builtin_bit_cast(f32x4, lo[1]);

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     for (int j = 0; j < 8; ++j) {
                         const float vs = fminf(fmaxf(v[j], -65504.f), 65504.f);    // saturate instead of inf/NaN pairs
                         hi[j] = (_Float16)vs;
-                        lo[j] = (_Float16)(vs - (float)hi[j]);
+                        lo[j] = lo_keep((_Float16)(vs - (float)hi[j]));
                     }
                     *reinterpret_cast<f32x4 *>(dst) = __builtin_bit_cast(f32x4, hi);
                     *reinterpret_cast<f32x4 *>(dst + 8) = __builtin_bit_cast(f32x4, lo);
