@@ -44,6 +44,9 @@
 #ifndef BSVD_TUNE_ALIGN
 #define BSVD_TUNE_ALIGN 1      // 1: 256-B aligned LDS patch row pitch (conflict-free A reads; +0.5 % in interleaved A/B)
 #endif
+#ifndef BSVD_TUNE_FAT_OCC
+#define BSVD_TUNE_FAT_OCC 2        // waves/SIMD the 128-accumulator tiles are compiled for
+#endif
 #ifndef BSVD_TUNE_D
 #define BSVD_TUNE_D 1          // patch slices stored D (1|2) taps after their load was issued
 #endif
@@ -93,7 +96,7 @@ struct ConvCfg {
     static_assert(NSLICE <= 7, "slices are loaded at taps 0..6 and stored two taps later (2..8)");
     // workgroups per CU the LDS footprint admits (160 KiB) -> register budget for __launch_bounds__
     static constexpr int OCC_LDS = LDS_BYTES > 80 * 1024 ? 1 : (LDS_BYTES > 53 * 1024 ? 2 : 3);
-    static constexpr int OCC = (MT * NT >= 8) ? 1 : OCC_LDS;   // 128 accumulator registers: one wave per SIMD, 512 registers
+    static constexpr int OCC = (MT * NT >= 8) ? BSVD_TUNE_FAT_OCC : OCC_LDS;   // 128 accumulator registers (AGPRs) + <= 128 VGPRs: two waves per SIMD
 };
 
 struct SrcSel {            // per-frame sources of the temporal-shift gather (wave uniform)
@@ -185,8 +188,16 @@ struct ChunkSrc {          // wave-uniform description of one 16-channel chunk's
 #ifndef BSVD_TUNE_S2F32_OCC
 #define BSVD_TUNE_S2F32_OCC 2      // waves/SIMD the exact-fp32 stride-2 kernel is compiled for (3 = 168 VGPRs + a 20-B spill: 2.3 % slower)
 #endif
+#ifndef BSVD_TUNE_FILL
+#define BSVD_TUNE_FILL 1           // 1: the whole LDS patch of a prologue / single-buffer refill in flight at once
+#endif
 template <class C, int PREC>
-constexpr int occ_of() { return (C::STRIDE == 2 && PREC == 0 && C::OCC > BSVD_TUNE_S2F32_OCC) ? BSVD_TUNE_S2F32_OCC : C::OCC; }
+constexpr int occ_of()
+{
+    // exact-fp32 stride 2 (single patch buffer): the refill holds the whole 17x33 patch in registers (72 VGPRs) -> 2 waves/SIMD
+    if (C::STRIDE == 2 && PREC == 0 && C::OCC > BSVD_TUNE_S2F32_OCC) return BSVD_TUNE_S2F32_OCC;
+    return C::OCC;
+}
 
 template <class C, bool FAST, int PREC>
 __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const ConvParams p)
@@ -331,14 +342,26 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         f32x4 b0[C::NT][2], b1[C::NT][2], b2[C::NT][2];
         load_b(0, b0);
         if constexpr (C::RING == 3) load_b(1, b1);
-        {
-            const ChunkSrc c = chunk_src(0);
+        // whole patch in flight at once, then published: one HBM latency per tile instead of one per slice
+        auto fill_patch = [&](const ChunkSrc &c, float *pb) {
+#if BSVD_TUNE_FILL
+          if constexpr (C::DBUF || PREC == 0) {
+            f32x4 v[C::NSLICE][C::P];
+#pragma unroll
+            for (int sl = 0; sl < C::NSLICE; ++sl) slice_load(c, sl * C::ROWS_PER_SLICE, v[sl]);
+#pragma unroll
+            for (int sl = 0; sl < C::NSLICE; ++sl) slice_store(pb, sl * C::ROWS_PER_SLICE, v[sl]);
+            return;
+          }
+#endif
+            // split-fp16 stride 2 keeps 3 waves/SIMD (72 more registers would cost one): one round trip per slice
             for (int row0 = 0; row0 < C::PH; row0 += C::ROWS_PER_SLICE) {
                 f32x4 v[C::P];
                 slice_load(c, row0, v);
-                slice_store(patch_buf, row0, v);
+                slice_store(pb, row0, v);
             }
-        }
+        };
+        fill_patch(chunk_src(0), patch_buf);
         __syncthreads();
 
         const int nsteps = ncb * 9;
@@ -397,13 +420,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
             }
             __syncthreads();   // one barrier per 16-channel chunk (9 taps, 288 MFMAs per wave)
             if constexpr (!C::DBUF) {
-                if (cb + 1 < ncb) {            // single buffer: everybody is done reading it -> refill, publish
-                    for (int row0 = 0; row0 < C::PH; row0 += C::ROWS_PER_SLICE) {
-                        f32x4 v[C::P];
-                        slice_load(cn, row0, v);
-                        slice_store(patch_buf, row0, v);
-                    }
-                }
+                if (cb + 1 < ncb) fill_patch(cn, patch_buf);   // single buffer: everybody is done reading it -> refill, publish
                 __syncthreads();
             }
         }
@@ -467,72 +484,105 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         //      lane finishes 8 channels of one pixel: bias/act/epilogue in fp32, split into (hi, lo), two 16-B stores.
         float *sc = smem + wid * (32 * 36);
         const int Cq = p.Cout >> 2;
+        // Everything the finishing lanes read from global memory is requested ahead of its use: the bias of this lane's
+        // 8 channels once per tile, the PixelShuffle skip operand one (mt, nt, it) item ahead.  (Issued inside the
+        // transposition loop, each of the 4*MT*NT items exposed a full memory round trip: ~10 us of a ~47 us tile.)
+        const int q = lane & 3;
+        f32x4 bq[C::NT][2];
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) {
+        for (int nt = 0; nt < C::NT; ++nt) {
+            const int n8 = n0 + wn * (C::NT * 32) + nt * 32 + q * 8;
+            bq[nt][0] = bq[nt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n8 < p.Cout) {
+                bq[nt][0] = *reinterpret_cast<const f32x4 *>(p.bias + n8);
+                bq[nt][1] = *reinterpret_cast<const f32x4 *>(p.bias + n8 + 4);
+            }
+        }
+        struct Item { bool live; int64_t opix; int n8, coff; };
+        auto item_of = [&](int i) {          // i = ((mt * NT + nt) * 2 + it), compile-time after unrolling
+            const int it = i & 1, nt = (i >> 1) % C::NT, mt = (i >> 1) / C::NT;
+            const int m = (lane + 64 * it) >> 2;
+            const int oy = oy0 + 2 * C::MT * wm + 2 * mt + (m >> 4);
+            const int ox = ox0 + (m & 15);
+            Item t;
+            t.n8 = n0 + wn * (C::NT * 32) + nt * 32 + q * 8;
+            t.live = oy < p.Ho && ox < p.Wo && t.n8 < p.Cout;
+            if (p.epilogue == BSVD_EPI_PS_ADD) {
+                const int sub = t.n8 / Cq, ch8 = t.n8 - sub * Cq;
+                t.opix = (int64_t)(2 * oy + (sub >> 1)) * (2 * p.Wo) + (2 * ox + (sub & 1));
+                t.coff = (ch8 >> 4) * 16 + ((ch8 >> 3) & 1) * 4;           // floats: chunk base + 8-channel half
+            } else {
+                t.opix = (int64_t)oy * p.Wo + ox;
+                t.coff = (t.n8 >> 4) * 16 + ((t.n8 >> 3) & 1) * 4;
+            }
+            return t;
+        };
+        const bool has_skip = p.epilogue == BSVD_EPI_PS_ADD && p.extra != nullptr;
+        auto skip_load = [&](const Item &t, f32x4 (&e)[2]) {               // skip tensor: split16, same layout as y
+            e[0] = e[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (has_skip && t.live) {
+                const float *ep = p.extra + (int64_t)f * p.extra_fs + t.opix * p.extra_ps + t.coff;
+                e[0] = *reinterpret_cast<const f32x4 *>(ep);
+                e[1] = *reinterpret_cast<const f32x4 *>(ep + 8);
+            }
+        };
+        constexpr int NITEM = C::MT * C::NT * 2;
+        f32x4 ecur[2], enxt[2];
+        skip_load(item_of(0), ecur);
 #pragma unroll
-            for (int nt = 0; nt < C::NT; ++nt) {
+        for (int i = 0; i < NITEM; ++i) {
+            const int it = i & 1, nt = (i >> 1) % C::NT, mt = (i >> 1) / C::NT;
+            if (i + 1 < NITEM) skip_load(item_of(i + 1), enxt);
+            if (it == 0) {
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[mt][nt][r];
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            const Item t = item_of(i);
+            const int m = (lane + 64 * it) >> 2;
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8);
+            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8 + 4);
+            if (t.live) {
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const int idx = lane + 64 * it;
-                    const int m = idx >> 2, q = idx & 3;
-                    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8 + 4);
-                    const int oy = oy0 + 2 * C::MT * wm + 2 * mt + (m >> 4);
-                    const int ox = ox0 + (m & 15);
-                    const int n8 = n0 + wn * (C::NT * 32) + nt * 32 + q * 8;
-                    if (oy >= p.Ho || ox >= p.Wo || n8 >= p.Cout) continue;
-                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    if (p.bias) {
-                        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(p.bias + n8);
-                        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(p.bias + n8 + 4);
+                for (int j = 0; j < 4; ++j) { v[j] += bq[nt][0][j]; v[4 + j] += bq[nt][1][j]; }
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+                for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], p.act);
+                float *dst;
+                if (p.epilogue == BSVD_EPI_PS_ADD) {
+                    if (has_skip) {
+                        const f16x8 eh = __builtin_bit_cast(f16x8, ecur[0]), el = __builtin_bit_cast(f16x8, ecur[1]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += (float)eh[j] + (float)el[j];
                     }
+                    dst = p.y + (int64_t)f * p.y_fs + t.opix * Cq + t.coff;
+                } else {
+                    if (p.epilogue == BSVD_EPI_RESID && t.n8 == 0) {                 // base: fp32 with generic strides
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], p.act);
-                    float *dst;
-                    if (p.epilogue == BSVD_EPI_PS_ADD) {
-                        const int sub = n8 / Cq, ch8 = n8 - sub * Cq;
-                        const int64_t opix = (int64_t)(2 * oy + (sub >> 1)) * (2 * p.Wo) + (2 * ox + (sub & 1));
-                        const int coff = (ch8 >> 4) * 16 + ((ch8 >> 3) & 1) * 4;       // floats: chunk base + 8-ch half
-                        if (p.extra) {                                                // skip tensor: split16, same layout as y
-                            const float *e = p.extra + (int64_t)f * p.extra_fs + opix * p.extra_ps + coff;
-                            const f16x8 eh = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(e));
-                            const f16x8 el = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(e + 8));
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] += (float)eh[j] + (float)el[j];
-                        }
-                        dst = p.y + (int64_t)f * p.y_fs + opix * Cq + coff;
-                    } else {
-                        const int64_t opix = (int64_t)oy * p.Wo + ox;
-                        if (p.epilogue == BSVD_EPI_RESID && n8 == 0) {                 // base: fp32 with generic strides
-#pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                if (j < p.resid_ch)
-                                    v[j] = p.extra[(int64_t)f * p.extra_fs + opix * p.extra_ps + (int64_t)j * p.extra_cs] - v[j];
-                        }
-                        dst = p.y + (int64_t)f * p.y_fs + opix * p.Cout + (n8 >> 4) * 16 + ((n8 >> 3) & 1) * 4;
+                        for (int j = 0; j < 8; ++j)
+                            if (j < p.resid_ch)
+                                v[j] = p.extra[(int64_t)f * p.extra_fs + t.opix * p.extra_ps + (int64_t)j * p.extra_cs] - v[j];
                     }
-                    f16x8 hi, lo;
+                    dst = p.y + (int64_t)f * p.y_fs + t.opix * p.Cout + t.coff;
+                }
+                f16x8 hi, lo;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float vs = fminf(fmaxf(v[j], -65504.f), 65504.f);    // saturate instead of inf/NaN pairs
-                        hi[j] = (_Float16)vs;
-                        lo[j] = lo_keep((_Float16)(vs - (float)hi[j]));
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    const float vs = fminf(fmaxf(v[j], -65504.f), 65504.f);    // saturate instead of inf/NaN pairs
+                    hi[j] = (_Float16)vs;
+                    lo[j] = lo_keep((_Float16)(vs - (float)hi[j]));
+                }
+                {
                     *reinterpret_cast<f32x4 *>(dst) = __builtin_bit_cast(f32x4, hi);
                     *reinterpret_cast<f32x4 *>(dst + 8) = __builtin_bit_cast(f32x4, lo);
                 }
             }
+            ecur[0] = enxt[0]; ecur[1] = enxt[1];
         }
-        return;
-    }
+    } else {
     // ---- epilogue.  C/D layout of 32x32 MFMA: col (n) = lane&31, row (m) = (r&3) + 8*(r>>2) + 4*(lane>>5);
     //      m -> pixel (row m>>4, col m&15) of the 2x16 pixel block of MFMA tile mt.
     const int Cq = p.Cout >> 2;   // PS_ADD: channels of the shuffled output
@@ -566,6 +616,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
             }
         }
     }
+    }   // PREC
 }
 
 template <class C, bool FAST, int PREC>
@@ -580,6 +631,8 @@ static int launch_cfg(const ConvParams &pin, hipStream_t stream, char *name = nu
     p.ntx = (p.Wo + C::TW - 1) / C::TW;
     p.nty = (p.Ho + C::TH - 1) / C::TH;
     p.nct = (p.Cout + C::BN - 1) / C::BN;
+    // (A persistent variant -- one round of resident workgroups walking all tiles -- was measured 4 % slower: it loses
+    //  the dispatcher's dynamic balancing and exposes every tile's prologue.)
     const int64_t nblk = (int64_t)p.frames * p.nty * p.ntx * p.nct;
     if (nblk <= 0 || nblk > 0x7fffffff) { set_error("bsvd_conv3x3: grid of %lld workgroups", (long long)nblk); return -1; }
     static std::atomic<int> granted[MAX_DEVICES];
