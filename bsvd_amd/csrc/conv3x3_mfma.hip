@@ -38,9 +38,13 @@
 //
 // Reference ops replaced: see include/bsvd_hip.h (bsvd_conv3x3).
 #include <stdio.h>
+#include <type_traits>
 #include "bsvd_internal.h"
 
 // tuning knobs (compile-time; the defaults are the measured best)
+#ifndef BSVD_TUNE_NT_STORE
+#define BSVD_TUNE_NT_STORE 0       // 1: split epilogue writes with the nontemporal hint
+#endif
 #ifndef BSVD_TUNE_ALIGN
 #define BSVD_TUNE_ALIGN 1      // 1: 256-B aligned LDS patch row pitch (conflict-free A reads; +0.5 % in interleaved A/B)
 #endif
@@ -487,6 +491,8 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         // Everything the finishing lanes read from global memory is requested ahead of its use: the bias of this lane's
         // 8 channels once per tile, the PixelShuffle skip operand one (mt, nt, it) item ahead.  (Issued inside the
         // transposition loop, each of the 4*MT*NT items exposed a full memory round trip: ~10 us of a ~47 us tile.)
+        // The item loop itself is specialised at compile time on (epilogue, activation) -- one uniform branch per tile
+        // instead of per value -- because at 2 waves/SIMD its VALU work is not hidden: ~10 % of a 128->128 layer.
         const int q = lane & 3;
         f32x4 bq[C::NT][2];
 #pragma unroll
@@ -498,90 +504,108 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 bq[nt][1] = *reinterpret_cast<const f32x4 *>(p.bias + n8 + 4);
             }
         }
-        struct Item { bool live; int64_t opix; int n8, coff; };
-        auto item_of = [&](int i) {          // i = ((mt * NT + nt) * 2 + it), compile-time after unrolling
-            const int it = i & 1, nt = (i >> 1) % C::NT, mt = (i >> 1) / C::NT;
-            const int m = (lane + 64 * it) >> 2;
-            const int oy = oy0 + 2 * C::MT * wm + 2 * mt + (m >> 4);
-            const int ox = ox0 + (m & 15);
-            Item t;
-            t.n8 = n0 + wn * (C::NT * 32) + nt * 32 + q * 8;
-            t.live = oy < p.Ho && ox < p.Wo && t.n8 < p.Cout;
-            if (p.epilogue == BSVD_EPI_PS_ADD) {
-                const int sub = t.n8 / Cq, ch8 = t.n8 - sub * Cq;
-                t.opix = (int64_t)(2 * oy + (sub >> 1)) * (2 * p.Wo) + (2 * ox + (sub & 1));
-                t.coff = (ch8 >> 4) * 16 + ((ch8 >> 3) & 1) * 4;           // floats: chunk base + 8-channel half
-            } else {
-                t.opix = (int64_t)oy * p.Wo + ox;
-                t.coff = (t.n8 >> 4) * 16 + ((t.n8 >> 3) & 1) * 4;
-            }
-            return t;
-        };
-        const bool has_skip = p.epilogue == BSVD_EPI_PS_ADD && p.extra != nullptr;
-        auto skip_load = [&](const Item &t, f32x4 (&e)[2]) {               // skip tensor: split16, same layout as y
-            e[0] = e[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (has_skip && t.live) {
-                const float *ep = p.extra + (int64_t)f * p.extra_fs + t.opix * p.extra_ps + t.coff;
-                e[0] = *reinterpret_cast<const f32x4 *>(ep);
-                e[1] = *reinterpret_cast<const f32x4 *>(ep + 8);
-            }
-        };
-        constexpr int NITEM = C::MT * C::NT * 2;
-        f32x4 ecur[2], enxt[2];
-        skip_load(item_of(0), ecur);
-#pragma unroll
-        for (int i = 0; i < NITEM; ++i) {
-            const int it = i & 1, nt = (i >> 1) % C::NT, mt = (i >> 1) / C::NT;
-            if (i + 1 < NITEM) skip_load(item_of(i + 1), enxt);
-            if (it == 0) {
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[mt][nt][r];
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            const Item t = item_of(i);
-            const int m = (lane + 64 * it) >> 2;
-            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8);
-            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8 + 4);
-            if (t.live) {
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j] += bq[nt][0][j]; v[4 + j] += bq[nt][1][j]; }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], p.act);
-                float *dst;
-                if (p.epilogue == BSVD_EPI_PS_ADD) {
-                    if (has_skip) {
-                        const f16x8 eh = __builtin_bit_cast(f16x8, ecur[0]), el = __builtin_bit_cast(f16x8, ecur[1]);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += (float)eh[j] + (float)el[j];
-                    }
-                    dst = p.y + (int64_t)f * p.y_fs + t.opix * Cq + t.coff;
+        auto finish = [&](auto epi_c, auto act_c) {
+            constexpr int EPI = decltype(epi_c)::value, ACT = decltype(act_c)::value;
+            struct Item { bool live; int64_t opix; int n8, coff; };
+            auto item_of = [&](int i) {          // i = ((mt * NT + nt) * 2 + it), compile-time after unrolling
+                const int it = i & 1, nt = (i >> 1) % C::NT, mt = (i >> 1) / C::NT;
+                const int m = (lane + 64 * it) >> 2;
+                const int oy = oy0 + 2 * C::MT * wm + 2 * mt + (m >> 4);
+                const int ox = ox0 + (m & 15);
+                Item t;
+                t.n8 = n0 + wn * (C::NT * 32) + nt * 32 + q * 8;
+                t.live = oy < p.Ho && ox < p.Wo && t.n8 < p.Cout;
+                if constexpr (EPI == BSVD_EPI_PS_ADD) {
+                    const int sub = t.n8 / Cq, ch8 = t.n8 - sub * Cq;
+                    t.opix = (int64_t)(2 * oy + (sub >> 1)) * (2 * p.Wo) + (2 * ox + (sub & 1));
+                    t.coff = (ch8 >> 4) * 16 + ((ch8 >> 3) & 1) * 4;           // floats: chunk base + 8-channel half
                 } else {
-                    if (p.epilogue == BSVD_EPI_RESID && t.n8 == 0) {                 // base: fp32 with generic strides
+                    t.opix = (int64_t)oy * p.Wo + ox;
+                    t.coff = (t.n8 >> 4) * 16 + ((t.n8 >> 3) & 1) * 4;
+                }
+                return t;
+            };
+            const bool has_skip = EPI == BSVD_EPI_PS_ADD && p.extra != nullptr;
+            auto skip_load = [&](const Item &t, f32x4 (&e)[2]) {               // skip tensor: split16, same layout as y
+                e[0] = e[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (has_skip && t.live) {
+                    const float *ep = p.extra + (int64_t)f * p.extra_fs + t.opix * p.extra_ps + t.coff;
+                    e[0] = *reinterpret_cast<const f32x4 *>(ep);
+                    e[1] = *reinterpret_cast<const f32x4 *>(ep + 8);
+                }
+            };
+            constexpr int NITEM = C::MT * C::NT * 2;
+            f32x4 ecur[2], enxt[2];
+            if constexpr (EPI == BSVD_EPI_PS_ADD) skip_load(item_of(0), ecur);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (j < p.resid_ch)
-                                v[j] = p.extra[(int64_t)f * p.extra_fs + t.opix * p.extra_ps + (int64_t)j * p.extra_cs] - v[j];
+            for (int i = 0; i < NITEM; ++i) {
+                const int it = i & 1, nt = (i >> 1) % C::NT, mt = (i >> 1) / C::NT;
+                if constexpr (EPI == BSVD_EPI_PS_ADD)
+                    if (i + 1 < NITEM) skip_load(item_of(i + 1), enxt);
+                if (it == 0) {
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[mt][nt][r];
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                const Item t = item_of(i);
+                const int m = (lane + 64 * it) >> 2;
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8 + 4);
+                if (t.live) {
+                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] += bq[nt][0][j]; v[4 + j] += bq[nt][1][j]; }
+                    // activation and the fp16 range guard in one v_med3 where possible (saturate instead of inf/NaN pairs)
+                    constexpr bool bounded = ACT == BSVD_ACT_RELU6 && EPI == BSVD_EPI_PLAIN;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if constexpr (ACT == BSVD_ACT_RELU6) v[j] = __builtin_amdgcn_fmed3f(v[j], 0.f, 6.f);
+                        else if constexpr (ACT == BSVD_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
                     }
-                    dst = p.y + (int64_t)f * p.y_fs + t.opix * p.Cout + t.coff;
-                }
-                f16x8 hi, lo;
+                    float *dst;
+                    if constexpr (EPI == BSVD_EPI_PS_ADD) {
+                        if (has_skip) {
+                            const f16x8 eh = __builtin_bit_cast(f16x8, ecur[0]), el = __builtin_bit_cast(f16x8, ecur[1]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float vs = fminf(fmaxf(v[j], -65504.f), 65504.f);    // saturate instead of inf/NaN pairs
-                    hi[j] = (_Float16)vs;
-                    lo[j] = lo_keep((_Float16)(vs - (float)hi[j]));
-                }
-                {
+                            for (int j = 0; j < 8; ++j) v[j] += (float)eh[j] + (float)el[j];
+                        }
+                        dst = p.y + (int64_t)f * p.y_fs + t.opix * Cq + t.coff;
+                    } else {
+                        if constexpr (EPI == BSVD_EPI_RESID) {
+                            if (t.n8 == 0) {                                           // base: fp32 with generic strides
+#pragma unroll
+                                for (int j = 0; j < 8; ++j)
+                                    if (j < p.resid_ch)
+                                        v[j] = p.extra[(int64_t)f * p.extra_fs + t.opix * p.extra_ps + (int64_t)j * p.extra_cs] - v[j];
+                            }
+                        }
+                        dst = p.y + (int64_t)f * p.y_fs + t.opix * p.Cout + t.coff;
+                    }
+                    f16x8 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float vs = bounded ? v[j] : __builtin_amdgcn_fmed3f(v[j], -65504.f, 65504.f);
+                        hi[j] = (_Float16)vs;
+                        lo[j] = lo_keep((_Float16)__builtin_fmaf((float)hi[j], -1.0f, vs));
+                    }
                     *reinterpret_cast<f32x4 *>(dst) = __builtin_bit_cast(f32x4, hi);
                     *reinterpret_cast<f32x4 *>(dst + 8) = __builtin_bit_cast(f32x4, lo);
                 }
+                if constexpr (EPI == BSVD_EPI_PS_ADD) { ecur[0] = enxt[0]; ecur[1] = enxt[1]; }
             }
-            ecur[0] = enxt[0]; ecur[1] = enxt[1];
-        }
+        };
+        using std::integral_constant;
+        auto with_act = [&](auto epi_c) {
+            if (p.act == BSVD_ACT_RELU6) finish(epi_c, integral_constant<int, BSVD_ACT_RELU6>{});
+            else if (p.act == BSVD_ACT_RELU) finish(epi_c, integral_constant<int, BSVD_ACT_RELU>{});
+            else finish(epi_c, integral_constant<int, BSVD_ACT_NONE>{});
+        };
+        if (p.epilogue == BSVD_EPI_PLAIN) with_act(integral_constant<int, BSVD_EPI_PLAIN>{});
+        else if (p.epilogue == BSVD_EPI_PS_ADD) with_act(integral_constant<int, BSVD_EPI_PS_ADD>{});
+        else with_act(integral_constant<int, BSVD_EPI_RESID>{});
     } else {
     // ---- epilogue.  C/D layout of 32x32 MFMA: col (n) = lane&31, row (m) = (r&3) + 8*(r>>2) + 4*(lane>>5);
     //      m -> pixel (row m>>4, col m&15) of the 2x16 pixel block of MFMA tile mt.
