@@ -240,7 +240,13 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
 
     // A fragments: per-lane offset into the LDS patch (floats)
     const int a_lane = ((2 * C::MT * wm + (li >> 4)) * C::STRIDE) * C::ROWP + ((li & 15) * C::STRIDE) * C::PS + lh * 4;
-    const int nb0 = n0 + wn * (C::NT * 32) + li;                 // this lane's output channel for nt = 0 (+32 per nt)
+    // The weights are the MFMA's A operand (rows = output channels) and the pixels its B operand (columns), so a lane ends
+    // up holding 16 output channels of ONE pixel: D row of register r is (r&3) + 8*(r>>2) + 4*lh.  Row i is fed with
+    // channel chan(i) such that registers 0..7 / 8..15 of a lane are 8 consecutive channels each (groups 2h + lh):
+    // the epilogue then stores 16-byte pieces straight from registers, no transposition through LDS.
+    const int rrow = (li & 3) + 4 * (li >> 3);                   // register index that holds row li (in lane half (li>>2)&1)
+    const int chan = 8 * (2 * (rrow >> 3) + ((li >> 2) & 1)) + (rrow & 7);
+    const int nb0 = n0 + wn * (C::NT * 32) + chan;               // output channel whose weights this lane loads for nt = 0 (+32 per nt)
 
     f32x16 acc[C::MT][C::NT];
 #pragma unroll
@@ -267,9 +273,9 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 for (int nt = 0; nt < C::NT; ++nt) {
                     const f16x8 ah = __builtin_bit_cast(f16x8, a[mt][0]), al = __builtin_bit_cast(f16x8, a[mt][1]);
                     const f16x8 bh = __builtin_bit_cast(f16x8, b[nt][0]), bl = __builtin_bit_cast(f16x8, b[nt][1]);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[mt][nt], 0, 0, 0);
                 }
             return;
         }
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < C::NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][g][j], b[nt][g][j], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[nt][g][j], a[mt][g][j], acc[mt][nt], 0, 0, 0);
     };
 
     if constexpr (FAST) {
@@ -482,165 +488,173 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         }
     }
 
-    if constexpr (PREC == 1) {
-        // ---- split16 epilogue: per 32x32 accumulator tile, transpose through a wave-private LDS scratch
-        //      ([32 px][32 ch + 4 pad] floats; the patch buffers are free after the last chunk's barrier), then every
-        //      lane finishes 8 channels of one pixel: bias/act/epilogue in fp32, split into (hi, lo), two 16-B stores.
-        float *sc = smem + wid * (32 * 36);
-        const int Cq = p.Cout >> 2;
-        // Everything the finishing lanes read from global memory is requested ahead of its use: the bias of this lane's
-        // 8 channels once per tile, the PixelShuffle skip operand one (mt, nt, it) item ahead.  (Issued inside the
-        // transposition loop, each of the 4*MT*NT items exposed a full memory round trip: ~10 us of a ~47 us tile.)
-        // The item loop itself is specialised at compile time on (epilogue, activation) -- one uniform branch per tile
-        // instead of per value -- because at 2 waves/SIMD its VALU work is not hidden: ~10 % of a 128->128 layer.
-        const int q = lane & 3;
-        f32x4 bq[C::NT][2];
+    // ---- epilogue.  Lane (li, lh) holds pixel li of the 2 x 16 pixel block of MFMA tile mt (row li>>4, column li&15)
+    //      and, per (mt, nt), two groups of 8 consecutive output channels: registers 8h..8h+7 = channels 8*(2h + lh)..+7
+    //      of the 32-channel tile.
+    //      exact fp32 : stored straight from registers, two 16-byte pieces per group (was 16 scalar stores per tile).
+    //      split16    : one pixel's 32 channels are 128 contiguous bytes and only ADJACENT lanes coalesce, so the tile is
+    //                   transposed through a wave-private LDS scratch ([32 px][32 ch + 4 pad] floats, four ds_write_b128
+    //                   per lane; the patch buffers are free after the last chunk's barrier) and 4 adjacent lanes finish
+    //                   the 4 x 8 channels of one pixel.  (Register-direct stores were tried here too: 4x the write
+    //                   transactions, 3-11 % slower on the 64-channel and stride-2 layers.)
+    //      Everything read from global memory is requested ahead of its use (bias once per tile, the PixelShuffle skip
+    //      operand one item ahead), and the item loop is specialised at compile time on (epilogue, activation): at 2-3
+    //      waves/SIMD its VALU work is not hidden behind other waves' MFMAs.
+    const int Cq = p.Cout >> 2;   // PS_ADD: channels of the shuffled output
+    constexpr int NB = PREC == 1 ? 1 : 2;                    // 8-channel groups per (lane, nt) whose bias is kept
+    const int q = lane & 3;
+    f32x4 bq[C::NT][NB][2];
 #pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt) {
-            const int n8 = n0 + wn * (C::NT * 32) + nt * 32 + q * 8;
-            bq[nt][0] = bq[nt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+        for (int h = 0; h < NB; ++h) {
+            const int n8 = n0 + wn * (C::NT * 32) + nt * 32 + (PREC == 1 ? 8 * q : 8 * (2 * h + lh));
+            bq[nt][h][0] = bq[nt][h][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.bias && n8 < p.Cout) {
-                bq[nt][0] = *reinterpret_cast<const f32x4 *>(p.bias + n8);
-                bq[nt][1] = *reinterpret_cast<const f32x4 *>(p.bias + n8 + 4);
+                bq[nt][h][0] = *reinterpret_cast<const f32x4 *>(p.bias + n8);
+                bq[nt][h][1] = *reinterpret_cast<const f32x4 *>(p.bias + n8 + 4);
             }
         }
-        auto finish = [&](auto epi_c, auto act_c) {
-            constexpr int EPI = decltype(epi_c)::value, ACT = decltype(act_c)::value;
-            struct Item { bool live; int64_t opix; int n8, coff; };
-            auto item_of = [&](int i) {          // i = ((mt * NT + nt) * 2 + it), compile-time after unrolling
-                const int it = i & 1, nt = (i >> 1) % C::NT, mt = (i >> 1) / C::NT;
-                const int m = (lane + 64 * it) >> 2;
-                const int oy = oy0 + 2 * C::MT * wm + 2 * mt + (m >> 4);
-                const int ox = ox0 + (m & 15);
-                Item t;
-                t.n8 = n0 + wn * (C::NT * 32) + nt * 32 + q * 8;
-                t.live = oy < p.Ho && ox < p.Wo && t.n8 < p.Cout;
-                if constexpr (EPI == BSVD_EPI_PS_ADD) {
-                    const int sub = t.n8 / Cq, ch8 = t.n8 - sub * Cq;
-                    t.opix = (int64_t)(2 * oy + (sub >> 1)) * (2 * p.Wo) + (2 * ox + (sub & 1));
-                    t.coff = (ch8 >> 4) * 16 + ((ch8 >> 3) & 1) * 4;           // floats: chunk base + 8-channel half
-                } else {
-                    t.opix = (int64_t)oy * p.Wo + ox;
-                    t.coff = (t.n8 >> 4) * 16 + ((t.n8 >> 3) & 1) * 4;
-                }
-                return t;
-            };
-            const bool has_skip = EPI == BSVD_EPI_PS_ADD && p.extra != nullptr;
-            auto skip_load = [&](const Item &t, f32x4 (&e)[2]) {               // skip tensor: split16, same layout as y
-                e[0] = e[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (has_skip && t.live) {
-                    const float *ep = p.extra + (int64_t)f * p.extra_fs + t.opix * p.extra_ps + t.coff;
-                    e[0] = *reinterpret_cast<const f32x4 *>(ep);
-                    e[1] = *reinterpret_cast<const f32x4 *>(ep + 8);
-                }
-            };
-            constexpr int NITEM = C::MT * C::NT * 2;
-            f32x4 ecur[2], enxt[2];
-            if constexpr (EPI == BSVD_EPI_PS_ADD) skip_load(item_of(0), ecur);
+    float *sc = smem + wid * (32 * 36);
+    auto finish = [&](auto epi_c, auto act_c) {
+        constexpr int EPI = decltype(epi_c)::value, ACT = decltype(act_c)::value;
+        struct Item { bool live; int64_t opix; int n8, c8; };
+        auto item_of = [&](int i) {          // i = ((mt * NT + nt) * 2 + s), compile-time after unrolling
+            const int sidx = i & 1, nt = (i >> 1) % C::NT, mt = (i >> 1) / C::NT;
+            int oy, ox;
+            Item t;
+            if constexpr (PREC == 1) {       // s = which 16 of the tile's 32 pixels; 4 adjacent lanes share a pixel
+                const int m = (lane + 64 * sidx) >> 2;
+                oy = oy0 + 2 * C::MT * wm + 2 * mt + (m >> 4);
+                ox = ox0 + (m & 15);
+                t.n8 = n0 + wn * (C::NT * 32) + nt * 32 + 8 * q;
+            } else {                         // s = h: which of the lane's two channel groups
+                oy = oy0 + 2 * C::MT * wm + 2 * mt + (li >> 4);
+                ox = ox0 + (li & 15);
+                t.n8 = n0 + wn * (C::NT * 32) + nt * 32 + 8 * (2 * sidx + lh);
+            }
+            t.live = oy < p.Ho && ox < p.Wo && t.n8 < p.Cout;
+            if constexpr (EPI == BSVD_EPI_PS_ADD) {
+                const int sub = t.n8 / Cq;
+                t.c8 = t.n8 - sub * Cq;                                      // first of 8 channels in the shuffled tensor
+                t.opix = (int64_t)(2 * oy + (sub >> 1)) * (2 * p.Wo) + (2 * ox + (sub & 1));
+            } else {
+                t.c8 = t.n8;
+                t.opix = (int64_t)oy * p.Wo + ox;
+            }
+            return t;
+        };
+        // split16: 8 channels = half a 16-channel chunk: hi at chunk*16 + half*4 floats, lo 8 floats further
+        auto coff16 = [](int c8) { return (c8 >> 4) * 16 + ((c8 >> 3) & 1) * 4; };
+        const bool has_skip = EPI == BSVD_EPI_PS_ADD && p.extra != nullptr;
+        auto skip_load = [&](const Item &t, f32x4 (&e)[2]) {
+            e[0] = e[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!(has_skip && t.live)) return;
+            if constexpr (PREC == 1) {                                       // split16 skip tensor, same layout as y
+                const float *ep = p.extra + (int64_t)f * p.extra_fs + t.opix * p.extra_ps + coff16(t.c8);
+                e[0] = *reinterpret_cast<const f32x4 *>(ep);
+                e[1] = *reinterpret_cast<const f32x4 *>(ep + 8);
+            } else {                                                         // fp32 skip tensor with generic strides
+                const float *ep = p.extra + (int64_t)f * p.extra_fs + t.opix * p.extra_ps + (int64_t)t.c8 * p.extra_cs;
 #pragma unroll
-            for (int i = 0; i < NITEM; ++i) {
-                const int it = i & 1, nt = (i >> 1) % C::NT, mt = (i >> 1) / C::NT;
-                if constexpr (EPI == BSVD_EPI_PS_ADD)
-                    if (i + 1 < NITEM) skip_load(item_of(i + 1), enxt);
-                if (it == 0) {
+                for (int j = 0; j < 8; ++j) e[j >> 2][j & 3] = ep[(int64_t)j * p.extra_cs];
+            }
+        };
+        constexpr int NITEM = C::MT * C::NT * 2;
+        f32x4 ecur[2], enxt[2];
+        if constexpr (EPI == BSVD_EPI_PS_ADD) skip_load(item_of(0), ecur);
+#pragma unroll
+        for (int i = 0; i < NITEM; ++i) {
+            const int sidx = i & 1, nt = (i >> 1) % C::NT, mt = (i >> 1) / C::NT;
+            if constexpr (EPI == BSVD_EPI_PS_ADD)
+                if (i + 1 < NITEM) skip_load(item_of(i + 1), enxt);
+            float v[8];
+            if constexpr (PREC == 1) {
+                if (sidx == 0) {             // stage this (mt, nt) tile: row = pixel li, 8 consecutive channels per write
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[mt][nt][r];
+                    for (int h = 0; h < 2; ++h) {
+                        float *w = sc + li * 36 + 8 * (2 * h + lh);
+                        const f32x16 &a = acc[mt][nt];
+                        *reinterpret_cast<f32x4 *>(w) = f32x4{a[8 * h], a[8 * h + 1], a[8 * h + 2], a[8 * h + 3]};
+                        *reinterpret_cast<f32x4 *>(w + 4) = f32x4{a[8 * h + 4], a[8 * h + 5], a[8 * h + 6], a[8 * h + 7]};
+                    }
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
-                const Item t = item_of(i);
-                const int m = (lane + 64 * it) >> 2;
+                const int m = (lane + 64 * sidx) >> 2;
                 const f32x4 v0 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8);
                 const f32x4 v1 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8 + 4);
-                if (t.live) {
-                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j] += bq[nt][0][j]; v[4 + j] += bq[nt][1][j]; }
-                    // activation and the fp16 range guard in one v_med3 where possible (saturate instead of inf/NaN pairs)
-                    constexpr bool bounded = ACT == BSVD_ACT_RELU6 && EPI == BSVD_EPI_PLAIN;
+                for (int j = 0; j < 4; ++j) { v[j] = v0[j] + bq[nt][0][0][j]; v[4 + j] = v1[j] + bq[nt][0][1][j]; }
+            } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if constexpr (ACT == BSVD_ACT_RELU6) v[j] = __builtin_amdgcn_fmed3f(v[j], 0.f, 6.f);
-                        else if constexpr (ACT == BSVD_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
-                    }
-                    float *dst;
-                    if constexpr (EPI == BSVD_EPI_PS_ADD) {
-                        if (has_skip) {
+                for (int j = 0; j < 8; ++j) v[j] = acc[mt][nt][8 * sidx + j] + bq[nt][sidx][j >> 2][j & 3];
+            }
+            const Item t = item_of(i);
+            if (t.live) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if constexpr (ACT == BSVD_ACT_RELU6) v[j] = __builtin_amdgcn_fmed3f(v[j], 0.f, 6.f);
+                    else if constexpr (ACT == BSVD_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+                }
+                if constexpr (EPI == BSVD_EPI_PS_ADD) {
+                    if (has_skip) {
+                        if constexpr (PREC == 1) {
                             const f16x8 eh = __builtin_bit_cast(f16x8, ecur[0]), el = __builtin_bit_cast(f16x8, ecur[1]);
 #pragma unroll
                             for (int j = 0; j < 8; ++j) v[j] += (float)eh[j] + (float)el[j];
-                        }
-                        dst = p.y + (int64_t)f * p.y_fs + t.opix * Cq + t.coff;
-                    } else {
-                        if constexpr (EPI == BSVD_EPI_RESID) {
-                            if (t.n8 == 0) {                                           // base: fp32 with generic strides
+                        } else {
 #pragma unroll
-                                for (int j = 0; j < 8; ++j)
-                                    if (j < p.resid_ch)
-                                        v[j] = p.extra[(int64_t)f * p.extra_fs + t.opix * p.extra_ps + (int64_t)j * p.extra_cs] - v[j];
-                            }
+                            for (int j = 0; j < 8; ++j) v[j] += ecur[j >> 2][j & 3];
                         }
-                        dst = p.y + (int64_t)f * p.y_fs + t.opix * p.Cout + t.coff;
                     }
+                }
+                if constexpr (EPI == BSVD_EPI_RESID) {
+                    if (t.n8 == 0) {                                         // base: fp32 with generic strides
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (j < p.resid_ch)
+                                v[j] = p.extra[(int64_t)f * p.extra_fs + t.opix * p.extra_ps + (int64_t)j * p.extra_cs] - v[j];
+                    }
+                }
+                const int cstride = EPI == BSVD_EPI_PS_ADD ? Cq : p.Cout;
+                if constexpr (PREC == 1) {
+                    float *dst = p.y + (int64_t)f * p.y_fs + t.opix * cstride + coff16(t.c8);
+                    constexpr bool bounded = ACT == BSVD_ACT_RELU6 && EPI == BSVD_EPI_PLAIN;
                     f16x8 hi, lo;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < 8; ++j) {        // fp16 range guard: saturate instead of inf/NaN pairs
                         const float vs = bounded ? v[j] : __builtin_amdgcn_fmed3f(v[j], -65504.f, 65504.f);
                         hi[j] = (_Float16)vs;
                         lo[j] = lo_keep((_Float16)__builtin_fmaf((float)hi[j], -1.0f, vs));
                     }
+#if BSVD_TUNE_NT_STORE
+                    __builtin_nontemporal_store(__builtin_bit_cast(f32x4, hi), reinterpret_cast<f32x4 *>(dst));
+                    __builtin_nontemporal_store(__builtin_bit_cast(f32x4, lo), reinterpret_cast<f32x4 *>(dst + 8));
+#else
                     *reinterpret_cast<f32x4 *>(dst) = __builtin_bit_cast(f32x4, hi);
                     *reinterpret_cast<f32x4 *>(dst + 8) = __builtin_bit_cast(f32x4, lo);
-                }
-                if constexpr (EPI == BSVD_EPI_PS_ADD) { ecur[0] = enxt[0]; ecur[1] = enxt[1]; }
-            }
-        };
-        using std::integral_constant;
-        auto with_act = [&](auto epi_c) {
-            if (p.act == BSVD_ACT_RELU6) finish(epi_c, integral_constant<int, BSVD_ACT_RELU6>{});
-            else if (p.act == BSVD_ACT_RELU) finish(epi_c, integral_constant<int, BSVD_ACT_RELU>{});
-            else finish(epi_c, integral_constant<int, BSVD_ACT_NONE>{});
-        };
-        if (p.epilogue == BSVD_EPI_PLAIN) with_act(integral_constant<int, BSVD_EPI_PLAIN>{});
-        else if (p.epilogue == BSVD_EPI_PS_ADD) with_act(integral_constant<int, BSVD_EPI_PS_ADD>{});
-        else with_act(integral_constant<int, BSVD_EPI_RESID>{});
-    } else {
-    // ---- epilogue.  C/D layout of 32x32 MFMA: col (n) = lane&31, row (m) = (r&3) + 8*(r>>2) + 4*(lane>>5);
-    //      m -> pixel (row m>>4, col m&15) of the 2x16 pixel block of MFMA tile mt.
-    const int Cq = p.Cout >> 2;   // PS_ADD: channels of the shuffled output
-#pragma unroll
-    for (int nt = 0; nt < C::NT; ++nt) {
-        const int n = n0 + wn * (C::NT * 32) + nt * 32 + li;
-        if (n >= p.Cout) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int oy = oy0 + 2 * C::MT * wm + 2 * mt + (m >> 4);
-                const int ox = ox0 + (m & 15);
-                if (oy >= p.Ho || ox >= p.Wo) continue;
-                float v = apply_act(acc[mt][nt][r] + bias, p.act);
-                if (p.epilogue == BSVD_EPI_PLAIN) {
-                    p.y[(int64_t)f * p.y_fs + ((int64_t)oy * p.Wo + ox) * p.Cout + n] = v;
-                } else if (p.epilogue == BSVD_EPI_PS_ADD) {
-                    const int sub = n / Cq, ch = n - sub * Cq;
-                    const int64_t opix = (int64_t)(2 * oy + (sub >> 1)) * (2 * p.Wo) + (2 * ox + (sub & 1));
-                    if (p.extra) v += p.extra[(int64_t)f * p.extra_fs + opix * p.extra_ps + (int64_t)ch * p.extra_cs];
-                    p.y[(int64_t)f * p.y_fs + opix * Cq + ch] = v;
-                } else {  // BSVD_EPI_RESID
-                    const int64_t opix = (int64_t)oy * p.Wo + ox;
-                    if (n < p.resid_ch)
-                        v = p.extra[(int64_t)f * p.extra_fs + opix * p.extra_ps + (int64_t)n * p.extra_cs] - v;
-                    p.y[(int64_t)f * p.y_fs + opix * p.Cout + n] = v;
+#endif
+                } else {
+                    float *dst = p.y + (int64_t)f * p.y_fs + t.opix * cstride + t.c8;
+                    *reinterpret_cast<f32x4 *>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4 *>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
                 }
             }
+            if constexpr (EPI == BSVD_EPI_PS_ADD) { ecur[0] = enxt[0]; ecur[1] = enxt[1]; }
         }
-    }
-    }   // PREC
+    };
+    using std::integral_constant;
+    auto with_act = [&](auto epi_c) {
+        if (p.act == BSVD_ACT_RELU6) finish(epi_c, integral_constant<int, BSVD_ACT_RELU6>{});
+        else if (p.act == BSVD_ACT_RELU) finish(epi_c, integral_constant<int, BSVD_ACT_RELU>{});
+        else finish(epi_c, integral_constant<int, BSVD_ACT_NONE>{});
+    };
+    if (p.epilogue == BSVD_EPI_PLAIN) with_act(integral_constant<int, BSVD_EPI_PLAIN>{});
+    else if (p.epilogue == BSVD_EPI_PS_ADD) with_act(integral_constant<int, BSVD_EPI_PS_ADD>{});
+    else with_act(integral_constant<int, BSVD_EPI_RESID>{});
 }
 
 template <class C, bool FAST, int PREC>
