@@ -123,27 +123,30 @@ __global__ __launch_bounds__(256) void head_kernel(const ConvParams p)
 }
 
 // ------------------------------------------------------------------------------------------------------
-// tail: workgroup = 16 x 16 pixels; per 16-channel chunk the 18 x 18 patch goes through LDS, thread = one pixel
+// tail: workgroup = 16 x 32 pixels, thread = two pixels 16 rows apart (the weights of a tap are read from LDS once and used
+// for both: 5 LDS reads per 24 FMAs instead of 4 per 12 -- the one-pixel version was LDS-issue bound).  Per 16-channel
+// chunk the 34 x 18 patch goes through a single LDS buffer: next chunk's loads are in flight during the 9 taps, stored
+// between two barriers.
 struct TailCfg {
-    static constexpr int T = 16, PWD = 18, PS = 20, NP = PWD * PWD, NQ = NP * 4;
-    static constexpr int PATCH_BYTES = 2 * NP * PS * 4;
+    static constexpr int TW = 16, TH = 32, PWD = TW + 2, PHT = TH + 2, PS = 20, NP = PWD * PHT, NQ = NP * 4;
+    static constexpr int PATCH_BYTES = NP * PS * 4;
     static constexpr int MAX_CHUNKS = 16;                       // Cin <= 256
     static int lds_bytes(int ncb, int cout) { return PATCH_BYTES + ncb * 36 * cout * 16; }
 };
 
 template <int COUT>
-__global__ __launch_bounds__(256) void tail_kernel(const ConvParams p, int y_planar_ch, int do_clamp, float lo, float hi)
+__global__ __launch_bounds__(256, 2) void tail_kernel(const ConvParams p, int y_planar_ch, int do_clamp, float lo, float hi)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using C = TailCfg;
     const int tid = threadIdx.x;
     const int px = tid & 15, py = tid >> 4;
-    const int ntx = (p.W + 15) >> 4, nty = (p.H + 15) >> 4;
+    const int ntx = (p.W + C::TW - 1) / C::TW, nty = (p.H + C::TH - 1) / C::TH;
     int bid = blockIdx.x;
     const int bx = bid % ntx; bid /= ntx;
     const int by = bid % nty;
     const int f = bid / nty;
-    const int ox0 = bx * 16, oy0 = by * 16;
+    const int ox0 = bx * C::TW, oy0 = by * C::TH;
     const float *xin = p.x + (int64_t)f * p.x_fs;
     const int ncb = p.Cin >> 4;
 
@@ -186,14 +189,16 @@ __global__ __launch_bounds__(256) void tail_kernel(const ConvParams p, int y_pla
             if (l_off[i] >= 0) *reinterpret_cast<f32x4 *>(buf + l_off[i]) = v[i];
     };
 
-    float acc[COUT];
+    float acc[2][COUT];
 #pragma unroll
-    for (int n = 0; n < COUT; ++n) acc[n] = 0.f;
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int n = 0; n < COUT; ++n) acc[u][n] = 0.f;
 
     // weights of the COUT live output channels -> LDS once per workgroup ([chunk][tap][k4][n][4]); every lane then reads
     // the same 16 bytes (LDS broadcast).  Scalar loads were the bottleneck here: 36 dependent s_load round trips per
     // chunk (1.25 ms per 10-frame clip vs 0.45 ms of HBM time).
-    float *wl = smem + 2 * C::NP * C::PS;
+    float *wl = smem + C::NP * C::PS;
     for (int e = tid; e < ncb * 36 * COUT; e += 256) {
         const int n = e % COUT, slab = e / COUT;            // slab = (cb*9 + tap)*4 + k4
         *reinterpret_cast<f32x4 *>(wl + e * 4) = *reinterpret_cast<const f32x4 *>(p.w + ((int64_t)slab * p.Cout + n) * 4);
@@ -204,39 +209,47 @@ __global__ __launch_bounds__(256) void tail_kernel(const ConvParams p, int y_pla
     stage_store(smem, st);
     __syncthreads();
     for (int cb = 0; cb < ncb; ++cb) {
-        const float *cur = smem + (cb & 1) * (C::NP * C::PS);
         if (cb + 1 < ncb) stage_load(cb + 1, st);          // in flight during this chunk's 9 taps
 #pragma unroll 1      // keep the 9 taps rolled: unrolled, hipcc preloads all 432 weight values and spills (512 VGPRs)
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
-            const float *ap = cur + ((py + ky) * C::PWD + (px + kx)) * C::PS;
-            f32x4 av[4];
+            const float *ap = smem + ((py + ky) * C::PWD + (px + kx)) * C::PS;
+            f32x4 av[2][4];
 #pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) av[k4] = *reinterpret_cast<const f32x4 *>(ap + k4 * 4);
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) av[u][k4] = *reinterpret_cast<const f32x4 *>(ap + u * (16 * C::PWD * C::PS) + k4 * 4);
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) {
-                const f32x4 a = av[k4];
                 const float *wt = wl + (((cb * 9 + tap) * 4 + k4) * COUT) * 4;               // [n][4], n = 0..COUT-1
 #pragma unroll
                 for (int n = 0; n < COUT; ++n) {
                     const f32x4 wv = *reinterpret_cast<const f32x4 *>(wt + n * 4);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[n] = fmaf(a[j], wv[j], acc[n]);
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[u][n] = fmaf(av[u][k4][j], wv[j], acc[u][n]);
                 }
             }
         }
-        if (cb + 1 < ncb) stage_store(smem + ((cb + 1) & 1) * (C::NP * C::PS), st);
-        __syncthreads();
+        if (cb + 1 < ncb) {
+            __syncthreads();                                // everybody is done reading the patch
+            stage_store(smem, st);
+            __syncthreads();
+        }
     }
 
-    const int ox = ox0 + px, oy = oy0 + py;
-    if (ox < p.W && oy < p.H) {
+    const int ox = ox0 + px;
+    const int64_t plane = (int64_t)p.H * p.W;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int oy = oy0 + py + 16 * u;
+        if (ox >= p.W || oy >= p.H) continue;
         const int64_t opix = (int64_t)oy * p.W + ox;
-        const int64_t plane = (int64_t)p.H * p.W;
 #pragma unroll
         for (int n = 0; n < COUT; ++n) {
             if (n >= y_planar_ch) break;
-            float v = edge_act(acc[n] + (p.bias ? as_const(p.bias)[n] : 0.f), p.act);
+            float v = edge_act(acc[u][n] + (p.bias ? as_const(p.bias)[n] : 0.f), p.act);
             if (p.epilogue == BSVD_EPI_RESID && n < p.resid_ch) {
                 float base;
                 if (p.extra_split) {           // split16 NHWC base: channel n < 16 lives in chunk 0
@@ -265,7 +278,7 @@ int launch_head_f32(const ConvParams &p, int cin_real, hipStream_t stream)
 
 int launch_tail_f32(const ConvParams &p, int cout_real, int do_clamp, float lo, float hi, hipStream_t stream)
 {
-    const int64_t nblk = (int64_t)p.frames * ((p.H + 15) / 16) * ((p.W + 15) / 16);
+    const int64_t nblk = (int64_t)p.frames * ((p.H + TailCfg::TH - 1) / TailCfg::TH) * ((p.W + TailCfg::TW - 1) / TailCfg::TW);
     if (nblk <= 0 || nblk > 0x7fffffff) { set_error("bsvd_conv3x3(tail): grid of %lld workgroups", (long long)nblk); return -1; }
     if (cout_real < 1 || cout_real > 4) { set_error("bsvd_conv3x3: planar output supports 1..4 channels, got %d", cout_real); return -15; }
     const int ncb = p.Cin >> 4;
