@@ -703,7 +703,13 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
         // the 64-channel layers: no gain over <2,2,4,1,1,3>.)  Stride 2: single patch buffer -> 3 workgroups/CU
         // instead of 1 (175 -> 287 TFLOP/s).
         if (!fast_ok(p, false)) { set_error("bsvd_conv3x3: BSVD_F16X3 needs fold %% 16 == 0 and 16-byte aligned operands"); return -17; }
-        if (stride == 2) return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, false>, true, 1>(p, stream, name, name_len);
+#ifndef BSVD_TUNE_S2_SPLIT
+#define BSVD_TUNE_S2_SPLIT 0       // 0: 8x16-px tile, single patch buffer; 1: 4x16-px tile, double-buffered
+#endif
+        if (stride == 2) {
+            if (BSVD_TUNE_S2_SPLIT == 1) return launch_cfg<ConvCfg<1, 2, 2, 2, 2, 3, true>, true, 1>(p, stream, name, name_len);
+            return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, false>, true, 1>(p, stream, name, name_len);
+        }
         // The fat tiles run one workgroup per CU, so they need a grid of several rounds of 256; small launches
         // (streaming mode: one frame per launch) keep the 64x64 tiles at 3 workgroups per CU.
         const int64_t fat_wide = (int64_t)p.frames * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16) * ((p.Cout + 127) / 128);
