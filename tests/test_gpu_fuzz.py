@@ -1,0 +1,76 @@
+"""Seeded random layer configurations through the C ABI vs the double-accumulating oracle executor: shapes, channel
+counts, strides, folds, epilogues and halo forms the hand-picked cases of test_gpu_parity.py / test_gpu_f16x3.py do not
+enumerate (ragged tiles in both directions, 1-pixel images, folds that force the generic gather, masked output columns)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _draw(rs, split):
+    epi = int(rs.choice([0, 0, 0, 1, 2]))
+    stride = 1 if epi else int(rs.choice([1, 1, 2]))
+    tsm = bool(epi == 0 and stride == 1 and rs.rand() < 0.4)
+    act = str(rs.choice(["relu6", "relu", "none"])) if epi == 0 else "none"
+    T = int(rs.randint(1, 4))
+    H, W = int(rs.randint(1, 41)), int(rs.randint(1, 41))
+    if split:
+        cin = int(rs.choice([128, 256])) if tsm else int(rs.choice([16, 32, 64, 128, 256]))
+        cout = int(rs.choice([64, 128, 256])) if epi == 1 else int(rs.choice([16, 32, 64, 128, 256]))
+        if tsm:
+            cout = cin
+    else:
+        cin = int(rs.choice([3, 8, 24, 30, 32, 40, 64, 100, 128]))
+        cout = int(rs.choice([64, 128, 192])) if epi == 1 else int(rs.choice([3, 5, 16, 30, 48, 64, 100, 128]))
+        if tsm and cin < 8:
+            cin = 24
+    if max(cin, cout) >= 128:            # keep the CPU oracle quick
+        H, W = min(H, 20), min(W, 24)
+    return cin, cout, stride, tsm, act, epi, T, H, W
+
+
+@pytest.mark.parametrize("seed", range(50))
+def test_random_layer_exact_fp32(seed):
+    import test_gpu_parity as P
+    args = _draw(np.random.RandomState(1000 + seed), split=False)
+    print("case", args)
+    P.test_layer_vs_oracle(*args)
+
+
+@pytest.mark.parametrize("seed", range(50))
+def test_random_layer_split_fp16(seed):
+    import test_gpu_f16x3 as S
+    args = _draw(np.random.RandomState(2000 + seed), split=True)
+    print("case", args)
+    S.test_layer_split_vs_oracle(*args)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_clip_whole_network(seed):
+    """bsvd_c64 on random small clips (any T >= 1, H and W multiples of 4 from 4 to 48): clip schedule vs the CPU oracle
+    in both arithmetic modes, stream schedule bit-identical, blind variant on odd seeds."""
+    import torch
+    import bsvd_amd
+    from helpers import bsvd_keys, maxabs
+    from seeded import seeded_state
+    from oracle import bsvd_oracle as O
+    rs = np.random.RandomState(3000 + seed)
+    T, H, W = int(rs.randint(1, 6)), 4 * int(rs.randint(1, 13)), 4 * int(rs.randint(1, 13))
+    blind = bool(seed & 1)
+    interm, act, cin = (30, "relu", 3) if blind else (64, "relu6", 4)
+    st = seeded_state(bsvd_keys([64, 128, 256], 64, 4, 3, interm, blind=blind), 40 + seed)
+    x = torch.from_numpy(rs.standard_normal((1, T, cin, H, W)).astype(np.float32))
+    cfg = O.default_cfg(act=act, interm_ch=interm, blind=blind)
+    want = O.bsvd_clip(x, O.to_torch_state(st), cfg)
+    dev = torch.device("cuda", 0)
+    for precision in ("fp32",) if blind else ("fp32", "f16x3"):       # f16x3 needs 16-aligned inner widths (interm 30 is not)
+        m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, in_ch=4, out_ch=3, norm="none", act=act, interm_ch=interm,
+                          blind=blind, pretrain_ckpt=None, precision=precision)
+        m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
+        m = m.to(dev)
+        y = m(x.to(dev))
+        err = maxabs(y.cpu().numpy(), want.numpy())
+        print("T=%d %dx%d blind=%s %s max-abs %.2e" % (T, H, W, blind, precision, err))
+        assert err < 1e-3
+        m.engine_mode = "stream"
+        assert torch.equal(m(x.to(dev)), y)
