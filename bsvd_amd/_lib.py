@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BSVD_HIP_LIB") or os.path.join(_HERE, "libbsvd_hip.so")   # env override: A/B tuning builds
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 BSVD_F32, BSVD_F16, BSVD_F16X3 = 0, 1, 2
 ACT = {"none": 0, "relu": 1, "relu6": 2}
 EPI_PLAIN, EPI_PS_ADD, EPI_RESID = 0, 1, 2

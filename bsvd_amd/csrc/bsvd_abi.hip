@@ -252,6 +252,7 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
     p.ablate = 0;
     p.prec = a->dtype == BSVD_F16X3 ? 1 : 0;
     p.extra_split = a->extra_split;
+    p.y_planar_ch = a->y_planar_ch; p.y_clamp = a->y_clamp; p.y_lo = a->y_lo; p.y_hi = a->y_hi;
 #ifdef BSVD_ABLATE
     if (const char *e = getenv("BSVD_ABLATE")) p.ablate = atoi(e);
 #endif
@@ -267,7 +268,11 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
         }
         if (a->Cout != 16 || a->epilogue == BSVD_EPI_PS_ADD) { set_error("bsvd_conv3x3: planar output needs Cout == 16 (padded) and PLAIN/RESID"); return -16; }
         if (a->epilogue == BSVD_EPI_RESID && a->resid_ch > a->y_planar_ch) { set_error("bsvd_conv3x3: resid_ch > y_planar_ch"); return -16; }
-        if (name) { snprintf(name, name_len, "tail_kernel<%d>%s", a->y_planar_ch == 3 ? 3 : 4, p.prec == 1 ? "[f16x3 in]" : "[f32]"); return 0; }
+        if (a->y_planar_ch > 4) { set_error("bsvd_conv3x3: planar output supports 1..4 channels, got %d", a->y_planar_ch); return -15; }
+        // split16: the exit layer runs on the matrix cores too (one 32-channel column tile, 3-4 of them live; weights
+        // split-packed like every other BSVD_F16X3 layer) and writes planar fp32 from its epilogue
+        if (p.prec == 1) return launch_conv3x3(p, 1, (hipStream_t)stream, name, name_len);
+        if (name) { snprintf(name, name_len, "tail_kernel<%d>[f32]", a->y_planar_ch == 3 ? 3 : 4); return 0; }
         return launch_tail_f32(p, a->y_planar_ch, a->y_clamp, a->y_lo, a->y_hi, (hipStream_t)stream);
     }
     return launch_conv3x3(p, a->stride, (hipStream_t)stream, name, name_len);

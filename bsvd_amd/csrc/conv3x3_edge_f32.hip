@@ -6,7 +6,8 @@
 //
 //   head_kernel<CIN>  : x planar NCHW [f][CIN][H][W] (the caller's tensor, bsvd_arch.py:494-499)
 //                       -> y NHWC [f][H][W][Cout_pad], bias + act.              (InputCvBlock conv 0, :208-209)
-//   tail_kernel<COUT> : x NHWC [f][H][W][Cin_pad] -> y planar NCHW [f][COUT][H][W], bias (+act),
+//   tail_kernel<COUT> : (exact-fp32 mode only; in split mode the exit layer runs on the MFMA kernel with a planar epilogue)
+//                       x NHWC [f][H][W][Cin_pad] -> y planar NCHW [f][COUT][H][W], bias (+act),
 //                       residual y[c] = base[c] - y[c] (c < resid_ch) and optional clamp.
 //                                                   (OutputCvBlock conv 3 :298, none_minus :408-414, clamp of
 //                                                    validation_seq_infer.py:24, torch.cat :552)
@@ -20,7 +21,6 @@ namespace bsvd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // Weights/bias are read-only for the whole launch and indexed wave-uniformly: reading them through the constant
 // address space lets the compiler use scalar loads (SGPR operands) even with stores in the same loop.
 typedef const __attribute__((address_space(4))) float *cfloat_p;
@@ -163,24 +163,11 @@ __global__ __launch_bounds__(256, 2) void tail_kernel(const ConvParams p, int y_
         g_off[i] = ok ? (iy * p.W + ix) * p.Cin + q * 4 : -1;      // < 2^31 elements per frame (checked by the host)
         l_off[i] = e < C::NQ ? pix * C::PS + q * 4 : -1;
     }
-    // split16 input: the item that would carry fp32 channels 4q..4q+3 instead reads the hi and lo halves of those
-    // channels (8 bytes each: hi at 2q*4 bytes, lo at 32 + 2q*4 bytes of the chunk) and rebuilds hi + lo, so the LDS
-    // patch always holds plain fp32 and every value is converted once, not once per tap.
     auto stage_load = [&](int cb, f32x4 (&v)[NI]) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (g_off[i] < 0) continue;
-            if (p.prec == 1) {
-                const int q = g_off[i] & 15;                                  // = 4 * quad index (elements)
-                const float *cbase = xin + (g_off[i] - q) + cb * 16;          // chunk base of this pixel
-                const f16x4 h = *reinterpret_cast<const f16x4 *>(reinterpret_cast<const _Float16 *>(cbase) + q);
-                const f16x4 l = *reinterpret_cast<const f16x4 *>(reinterpret_cast<const _Float16 *>(cbase) + 16 + q);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[i][j] = (float)h[j] + (float)l[j];
-            } else {
-                v[i] = *reinterpret_cast<const f32x4 *>(xin + g_off[i] + cb * 16);
-            }
+            if (g_off[i] >= 0) v[i] = *reinterpret_cast<const f32x4 *>(xin + g_off[i] + cb * 16);
         }
     };
     auto stage_store = [&](float *buf, const f32x4 (&v)[NI]) {
@@ -251,14 +238,7 @@ __global__ __launch_bounds__(256, 2) void tail_kernel(const ConvParams p, int y_
             if (n >= y_planar_ch) break;
             float v = edge_act(acc[u][n] + (p.bias ? as_const(p.bias)[n] : 0.f), p.act);
             if (p.epilogue == BSVD_EPI_RESID && n < p.resid_ch) {
-                float base;
-                if (p.extra_split) {           // split16 NHWC base: channel n < 16 lives in chunk 0
-                    const _Float16 *e = reinterpret_cast<const _Float16 *>(p.extra + (int64_t)f * p.extra_fs + opix * p.extra_ps);
-                    base = (float)e[n] + (float)e[16 + n];
-                } else {
-                    base = p.extra[(int64_t)f * p.extra_fs + opix * p.extra_ps + (int64_t)n * p.extra_cs];
-                }
-                v = base - v;
+                v = p.extra[(int64_t)f * p.extra_fs + opix * p.extra_ps + (int64_t)n * p.extra_cs] - v;
             }
             if (do_clamp) v = fminf(fmaxf(v, lo), hi);
             p.y[(int64_t)f * p.y_fs + n * plane + opix] = v;

@@ -500,6 +500,41 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
     //      Everything read from global memory is requested ahead of its use (bias once per tile, the PixelShuffle skip
     //      operand one item ahead), and the item loop is specialised at compile time on (epilogue, activation): at 2-3
     //      waves/SIMD its VALU work is not hidden behind other waves' MFMAs.
+    if constexpr (PREC == 1 && C::NT == 1) {
+        // network exit in split mode: channels 0..7 of the single 32-channel tile sit in registers 0..7 of lane half 0;
+        // the y_planar_ch live ones go out as planar fp32 [frames][ch][H][W] with the residual (DenBlock.none_minus,
+        // bsvd_arch.py:408-414) and the callers' clamp (validation_seq_infer.py:24) fused.  32 lanes = 2 rows x 16
+        // consecutive pixels: 64-byte runs per channel.
+        if (p.y_planar_ch > 0) {
+            if (lh == 0 && n0 == 0) {
+                const int64_t plane = (int64_t)p.Ho * p.Wo;
+#pragma unroll
+                for (int mt = 0; mt < C::MT; ++mt) {
+                    const int oy = oy0 + 2 * C::MT * wm + 2 * mt + (li >> 4), ox = ox0 + (li & 15);
+                    if (oy >= p.Ho || ox >= p.Wo) continue;
+                    const int64_t opix = (int64_t)oy * p.Wo + ox;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        if (n >= p.y_planar_ch) break;
+                        float v = apply_act(acc[mt][0][n] + (p.bias ? p.bias[n] : 0.f), p.act);
+                        if (p.epilogue == BSVD_EPI_RESID && n < p.resid_ch) {
+                            float base;
+                            if (p.extra_split) {       // split16 NHWC base: channel n < 16 lives in chunk 0
+                                const _Float16 *e = reinterpret_cast<const _Float16 *>(p.extra + (int64_t)f * p.extra_fs + opix * p.extra_ps);
+                                base = (float)e[n] + (float)e[16 + n];
+                            } else {
+                                base = p.extra[(int64_t)f * p.extra_fs + opix * p.extra_ps + (int64_t)n * p.extra_cs];
+                            }
+                            v = base - v;
+                        }
+                        if (p.y_clamp) v = fminf(fmaxf(v, p.y_lo), p.y_hi);
+                        p.y[(int64_t)f * p.y_fs + n * plane + opix] = v;
+                    }
+                }
+            }
+            return;
+        }
+    }
     const int Cq = p.Cout >> 2;   // PS_ADD: channels of the shuffled output
     constexpr int NB = PREC == 1 ? 1 : 2;                    // 8-channel groups per (lane, nt) whose bias is kept
     const int q = lane & 3;
@@ -661,8 +696,8 @@ template <class C, bool FAST, int PREC>
 static int launch_cfg(const ConvParams &pin, hipStream_t stream, char *name = nullptr, int name_len = 0)
 {
     if (name) {      // dry run: report the instantiation bsvd_conv3x3 would launch (used by bench.py's per-kernel timing)
-        snprintf(name, name_len, "conv3x3_kernel<%d,%d,%d,%d,%d>[%s]%s", C::MT, C::NT, C::WM, C::WN, C::STRIDE,
-                 PREC == 1 ? "f16x3" : "f32", FAST ? "" : "[generic]");
+        snprintf(name, name_len, "conv3x3_kernel<%d,%d,%d,%d,%d>[%s]%s%s", C::MT, C::NT, C::WM, C::WN, C::STRIDE,
+                 PREC == 1 ? "f16x3" : "f32", FAST ? "" : "[generic]", pin.y_planar_ch > 0 ? "[planar out]" : "");
         return 0;
     }
     ConvParams p = pin;
@@ -706,6 +741,10 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
 #ifndef BSVD_TUNE_S2_SPLIT
 #define BSVD_TUNE_S2_SPLIT 0       // 0: 8x16-px tile, single patch buffer; 1: 4x16-px tile, double-buffered
 #endif
+        if (p.y_planar_ch > 0) {         // network exit: 256 px x 32 ch tiles, planar fp32 epilogue
+            if (stride != 1 || p.fold != 0 || p.Cout > 32) { set_error("bsvd_conv3x3: planar split output needs stride 1, fold 0, Cout <= 32"); return -16; }
+            return launch_cfg<ConvCfg<2, 1, 4, 1, 1, 3>, true, 1>(p, stream, name, name_len);
+        }
         if (stride == 2) {
             if (BSVD_TUNE_S2_SPLIT == 1) return launch_cfg<ConvCfg<1, 2, 2, 2, 2, 3, true>, true, 1>(p, stream, name, name_len);
             return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, false>, true, 1>(p, stream, name, name_len);

@@ -35,8 +35,9 @@ class PackedNet:
         self.tensors = {}
         edge = set()
         if precision == "f16x3":
-            # the edge layers run on the fp32 VALU kernels (planar in / planar out) and keep fp32 packs
-            edge = {net.layers[0].key, net.layers[-1].key}
+            # the entry layer (planar 3/4-channel input) runs on the fp32 VALU kernel and keeps an fp32 pack; every other
+            # layer, the planar-output exit layer included, is split-packed for the MFMA kernel
+            edge = {net.layers[0].key}
         with torch.cuda.device(device):
             for sp in net.layers:
                 w = state[sp.key + ".weight"].detach().to(device=device, dtype=torch.float32).contiguous()

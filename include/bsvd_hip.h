@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BSVD_ABI_VERSION 4
+#define BSVD_ABI_VERSION 5
 
 /* dtype.  BSVD_F32: exact fp32 (v_mfma_f32_32x32x2_f32).  BSVD_F16X3 ("split16"): every fp32 value v is carried as
  * an fp16 pair hi = fp16(v), lo = fp16(v - hi); a 16-channel chunk of a pixel is stored as [hi x16 | lo x16] in the
@@ -93,7 +93,10 @@ typedef struct BsvdConvArgs {
      *                    BSVD.forward's reshaped input, bsvd_arch.py:494-499); needs Cin == 16, stride 1, fold 0, PLAIN.
      *   y_planar_ch > 0: y is planar [frames][y_planar_ch][H][W] fp32 (1..4 channels, the tensor torch.cat(out_seq)
      *                    returns, :552); needs Cout == 16, stride 1, fold 0, PLAIN or RESID; y_clamp != 0 additionally
-     *                    clamps to [y_lo, y_hi] (the callers' torch.clamp, validation_seq_infer.py:24). */
+     *                    clamps to [y_lo, y_hi] (the callers' torch.clamp, validation_seq_infer.py:24).
+     * Weights of these two layers: the planar-INPUT layer always takes an fp32 pack (bsvd_pack_weights dtype BSVD_F32; it
+     * runs on a VALU kernel and, in BSVD_F16X3, writes split16).  The planar-OUTPUT layer takes the pack of its dtype: in
+     * BSVD_F16X3 it is an MFMA layer like any other (split-packed weights, split16 input). */
     int32_t x_planar_ch, y_planar_ch, y_clamp;
     float y_lo, y_hi;
     int32_t extra_split;        /* BSVD_F16X3 + y_planar_ch: the RESID base `extra` is a split16 NHWC tensor (extra_pstride

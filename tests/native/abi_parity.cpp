@@ -143,9 +143,9 @@ static void case_split_chain() {
     auto w2 = randv((size_t)C * C * 9, 0.06f), b2 = randv(C, 0.1f);
     auto w3 = randv((size_t)3 * C * 9, 0.06f), b3 = randv(3, 0.1f);
     float *dx = dev(x), *d1 = dev_zeros((size_t)T * H * W * C), *d2 = dev_zeros((size_t)T * H * W * C), *dy = dev_zeros((size_t)T * 3 * H * W);
-    Packed p1 = pack(w1, b1, 4, C, 16, C, 0, BSVD_F32);          // edge layers keep fp32 packs (VALU kernels)
+    Packed p1 = pack(w1, b1, 4, C, 16, C, 0, BSVD_F32);          // the entry layer keeps an fp32 pack (VALU kernel)
     Packed p2 = pack(w2, b2, C, C, C, C, 0, BSVD_F16X3);
-    Packed p3 = pack(w3, b3, C, 3, C, 16, 0, BSVD_F32);
+    Packed p3 = pack(w3, b3, C, 3, C, 16, 0, BSVD_F16X3);        // the exit layer is an MFMA layer too
     BsvdConvArgs a; memset(&a, 0, sizeof(a));
     a.x = dx; a.x_frame_stride = (int64_t)4 * H * W; a.x_planar_ch = 4; a.w_packed = p1.w; a.bias_packed = p1.b;
     a.y = d1; a.y_frame_stride = (int64_t)H * W * C; a.frames = T; a.H = H; a.W = W; a.Cin = 16; a.Cout = C; a.stride = 1;
