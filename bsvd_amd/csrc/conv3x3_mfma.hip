@@ -192,6 +192,9 @@ struct ChunkSrc {          // wave-uniform description of one 16-channel chunk's
 #ifndef BSVD_TUNE_S2F32_OCC
 #define BSVD_TUNE_S2F32_OCC 2      // waves/SIMD the exact-fp32 stride-2 kernel is compiled for (3 = 168 VGPRs + a 20-B spill: 2.3 % slower)
 #endif
+#ifndef BSVD_TUNE_S2_GROUP
+#define BSVD_TUNE_S2_GROUP 1       // slices per round trip of the split-fp16 stride-2 patch refill
+#endif
 #ifndef BSVD_TUNE_FILL
 #define BSVD_TUNE_FILL 1           // 1: the whole LDS patch of a prologue / single-buffer refill in flight at once
 #endif
@@ -354,21 +357,19 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         if constexpr (C::RING == 3) load_b(1, b1);
         // whole patch in flight at once, then published: one HBM latency per tile instead of one per slice
         auto fill_patch = [&](const ChunkSrc &c, float *pb) {
-#if BSVD_TUNE_FILL
-          if constexpr (C::DBUF || PREC == 0) {
-            f32x4 v[C::NSLICE][C::P];
+            // G slices in flight at once, then published.  Everything at once where the registers are there (prologue of
+            // the double-buffered tiles, exact-fp32 stride 2 at 2 waves/SIMD); the split-fp16 stride-2 tile stays at 3
+            // waves/SIMD and takes BSVD_TUNE_S2_GROUP slices per round trip.
+            constexpr int G = (BSVD_TUNE_FILL && (C::DBUF || PREC == 0)) ? C::NSLICE : BSVD_TUNE_S2_GROUP;
 #pragma unroll
-            for (int sl = 0; sl < C::NSLICE; ++sl) slice_load(c, sl * C::ROWS_PER_SLICE, v[sl]);
+            for (int g0 = 0; g0 < C::NSLICE; g0 += G) {
+                f32x4 v[G][C::P];
 #pragma unroll
-            for (int sl = 0; sl < C::NSLICE; ++sl) slice_store(pb, sl * C::ROWS_PER_SLICE, v[sl]);
-            return;
-          }
-#endif
-            // split-fp16 stride 2 keeps 3 waves/SIMD (72 more registers would cost one): one round trip per slice
-            for (int row0 = 0; row0 < C::PH; row0 += C::ROWS_PER_SLICE) {
-                f32x4 v[C::P];
-                slice_load(c, row0, v);
-                slice_store(pb, row0, v);
+                for (int sl = 0; sl < G; ++sl)
+                    if (g0 + sl < C::NSLICE) slice_load(c, (g0 + sl) * C::ROWS_PER_SLICE, v[sl]);
+#pragma unroll
+                for (int sl = 0; sl < G; ++sl)
+                    if (g0 + sl < C::NSLICE) slice_store(pb, (g0 + sl) * C::ROWS_PER_SLICE, v[sl]);
             }
         };
         fill_patch(chunk_src(0), patch_buf);
