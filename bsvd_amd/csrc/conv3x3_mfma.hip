@@ -206,12 +206,30 @@ constexpr int occ_of()
     return C::OCC;
 }
 
+#ifdef BSVD_TIMELINE
+// Measurement build (tools/timeline.py): wave 0 of every workgroup stamps s_memrealtime (100 MHz) at entry, after the
+// prologue barrier, after the K loop and at exit, plus its hardware id (XCD / SE / CU / SIMD slot).
+#define BSVD_TIMELINE_SLOTS (1 << 16)
+__device__ unsigned long long g_timeline[BSVD_TIMELINE_SLOTS][8];
+__device__ __forceinline__ void tl_stamp(int slot, int k)
+{
+    if (threadIdx.x == 0 && slot < BSVD_TIMELINE_SLOTS) {
+        g_timeline[slot][k] = __builtin_amdgcn_s_memrealtime();
+        if (k == 0) g_timeline[slot][4] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20 /* XCC_ID */) << 32) |
+                                          (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_ID, 32 bits */);
+    }
+}
+#define TL(k) tl_stamp(blockIdx.x, k)
+#else
+#define TL(k)
+#endif
 template <class C, bool FAST, int PREC>
 __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *const patch_buf = smem;                              // 2 x PATCH_FLOATS
 
+    TL(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -374,6 +392,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         };
         fill_patch(chunk_src(0), patch_buf);
         __syncthreads();
+        TL(1);
 
         const int nsteps = ncb * 9;
         int step = 0;
@@ -489,6 +508,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         }
     }
 
+    TL(2);
     // ---- epilogue.  Lane (li, lh) holds pixel li of the 2 x 16 pixel block of MFMA tile mt (row li>>4, column li&15)
     //      and, per (mt, nt), two groups of 8 consecutive output channels: registers 8h..8h+7 = channels 8*(2h + lh)..+7
     //      of the 32-channel tile.
@@ -680,6 +700,8 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 }
             }
             if constexpr (EPI == BSVD_EPI_PS_ADD) { ecur[0] = enxt[0]; ecur[1] = enxt[1]; }
+            if (i == 0) TL(5);
+            if (i == NITEM / 2 - 1) TL(6);
         }
     };
     using std::integral_constant;
@@ -691,6 +713,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
     if (p.epilogue == BSVD_EPI_PLAIN) with_act(integral_constant<int, BSVD_EPI_PLAIN>{});
     else if (p.epilogue == BSVD_EPI_PS_ADD) with_act(integral_constant<int, BSVD_EPI_PS_ADD>{});
     else with_act(integral_constant<int, BSVD_EPI_RESID>{});
+    TL(3);
 }
 
 template <class C, bool FAST, int PREC>
@@ -766,3 +789,10 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
 }
 
 }  // namespace bsvd
+
+#ifdef BSVD_TIMELINE
+extern "C" int bsvd_debug_timeline(unsigned long long *dst, int n)     // measurement builds only; not in include/bsvd_hip.h
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(bsvd::g_timeline), sizeof(unsigned long long) * 8 * (size_t)n);
+}
+#endif
