@@ -59,9 +59,11 @@ class _HipNet(nn.Module):
         self.clamp = clamp
         self.precision = precision
         if precision == "f16x3":
-            bad = [l.key for l in net.layers[1:-1] if l.cin % 16 or l.cout % 16 or (l.tsm and l.fold % 16)]
+            # channel counts that are not multiples of 16 ride on zero padding channels (e.g. interm_ch = 30 of the blind
+            # config); a temporal-fusion layer needs whole 16-channel chunks per temporal source: fold % 16 == 0
+            bad = [l.key for l in net.layers if l.tsm and l.fold % 16]
             if bad or net.net_in_ch not in (3, 4) or net.out_ch > 4:
-                raise ValueError("precision='f16x3' needs 16-aligned channel counts, fold % 16 == 0 (chns[1:] multiples "
+                raise ValueError("precision='f16x3' needs fold % 16 == 0 in the temporal-fusion layers (chns[1:] multiples "
                                  "of 128) and <= 4 input/output channels; offending layers: %s" % (bad[:3],))
         self._packed = None
         self._packed_sig = None
@@ -147,7 +149,7 @@ class BSVD(_HipNet):
                     validation_seq_infer.py:24).
       precision   : 'fp32' (default; exact fp32 MFMA, bitwise an fmaf chain) or 'f16x3' (split-fp16 3-pass MFMA with
                     fp32 accumulation: fp32-class accuracy -- 2-4e-5 max-abs on bsvd_c64, budget 1e-3 -- at several
-                    times the throughput).  'f16x3' needs chns[1:] multiples of 128 and 16-aligned inner widths.
+                    times the throughput).  'f16x3' needs chns[1:] multiples of 128 (fold % 16 == 0).
     """
 
     def __init__(self, chns=[32, 64, 128], mid_ch=3, shift_input=False, in_ch=4, out_ch=3, norm='bn', act='relu',
