@@ -226,6 +226,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # single node: keep gloo's and RCCL's socket bootstrap on loopback (the container hostname may not resolve);
+        # the halo payload itself travels over xGMI peer-to-peer, not over sockets
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         halo_group, halo_transport = init_groups(dist, device, rank, world)
 
     lq, nm = synth_clip(args.frames, 100 + rank, device)       # this rank's window of the 10*N-frame clip
