@@ -147,6 +147,8 @@ class BSVD(_HipNet):
                     the clip's activations fit the free HBM, else 'stream').  Same function, bit-identical results.
       clamp       : optional (lo, hi) fused into the exit kernel (callers clamp to [0,1] anyway,
                     validation_seq_infer.py:24).
+      stream_overlap : streaming_forward runs the two DenBlocks of consecutive steps on two HIP streams (default True;
+                    same results, bit for bit).
       precision   : 'fp32' (default; exact fp32 MFMA, bitwise an fmaf chain) or 'f16x3' (split-fp16 3-pass MFMA with
                     fp32 accumulation: fp32-class accuracy -- 2-4e-5 max-abs on bsvd_c64, budget 1e-3 -- at several
                     times the throughput).  'f16x3' needs chns[1:] multiples of 128 (fold % 16 == 0).
@@ -154,7 +156,7 @@ class BSVD(_HipNet):
 
     def __init__(self, chns=[32, 64, 128], mid_ch=3, shift_input=False, in_ch=4, out_ch=3, norm='bn', act='relu',
                  interm_ch=30, blind=False, pretrain_ckpt='./experiments/pretrained_ckpt/bsvd-64.pth',
-                 engine_mode='auto', clamp=None, precision='fp32'):
+                 engine_mode='auto', clamp=None, precision='fp32', stream_overlap=True):
         super().__init__()
         if shift_input:
             raise NotImplementedError("shift_input=True (CvBlock input stage) is not used by any BSVD config; "
@@ -167,6 +169,8 @@ class BSVD(_HipNet):
         self._init_engine(make_netspec(chns, mid_ch, in_ch, out_ch, act, interm_ch, blind), precision, clamp)
         self.engine_mode = engine_mode
         self.last_mode = None          # schedule the last forward() actually ran ('clip' | 'stream')
+        self.stream_overlap = bool(stream_overlap)   # streaming_forward: temp1(t+1) and temp2(t) on two HIP streams
+        self._ab_streams = None
         # Same RNG consumption as the reference constructor (each DenBlock re-initialises itself, then BSVD does it
         # again, bsvd_arch.py:350,453): a seeded run draws the same weights AND leaves the generator in the same state,
         # so the evaluation noise that follows (ValFolderDataset) is the reference's realisation.
@@ -221,6 +225,8 @@ class BSVD(_HipNet):
         if isinstance(input_seq, torch.Tensor):
             input_seq = [input_seq[i:i + 1] for i in np.arange(input_seq.shape[0])]
         assert type(input_seq) == list, "convert the input into a sequence"
+        if self.stream_overlap and len(input_seq) > 0:
+            return self._streaming_forward_overlapped(input_seq)
         outs = []
         try:
             for x in input_seq:
@@ -232,6 +238,59 @@ class BSVD(_HipNet):
             if self._pipe is not None:
                 self._pipe.clear()             # also after an exception: never leave stale buffers behind
         return torch.cat(outs[self.shift_num:], dim=0)
+
+    def _streaming_forward_overlapped(self, input_seq):
+        """Same pipeline, same kernels, same results as the loop above, but the two DenBlocks of consecutive steps run on
+        two HIP streams: temp2 of step t (stream B) overlaps temp1 of step t+1 (stream A).  The frames=1 launches of the
+        quarter-resolution layers do not fill 256 CUs on their own; two independent launch queues do (+8 % measured with
+        two unrelated streams, tools/concurrent_streams.py).  Only possible here, where the whole list is in hand: the
+        per-frame API (feedin_one_element) must hand its result to the caller's stream before it returns."""
+        dev = self._device()
+        F = len(input_seq)
+        with torch.no_grad(), torch.cuda.device(dev):
+            ex = self._executor(dev)
+            if self._pipe is None:
+                self._pipe = StreamPipeline(self.net)
+            pipe = self._pipe
+            if self._ab_streams is None:
+                self._ab_streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+            sa, sb = self._ab_streams
+            cur = torch.cuda.current_stream(dev)
+            pin, pout = planar_ok(ex, self.net)
+            out_dtype = input_seq[0].dtype if input_seq[0].dtype in (torch.float16, torch.bfloat16) else torch.float32
+            sa.wait_stream(cur)
+            sb.wait_stream(cur)
+            outs = []
+            try:
+                for step in range(F + self.shift_num + 1):           # incl. the reference's extra, discarded flush call
+                    x = input_seq[step] if step < F else None
+                    with torch.cuda.stream(sa):
+                        xin = None
+                        if x is not None:
+                            xin = x.to(device=dev, dtype=torch.float32).contiguous()
+                            xin.record_stream(sa)                   # may alias the caller's tensor; kept in temp1's FIFO
+                            if not pin:
+                                xin = ex.to_nhwc(xin, self.net.temp1["inc0"].cin_pad)
+                        y1 = pipe.t1.feed(ex, xin, x_planar=pin)
+                    sb.wait_stream(sa)                              # everything of temp1(step); temp1(step+1) comes later
+                    with torch.cuda.stream(sb):
+                        y = pipe.t2.feed(ex, y1, y_planar=(self.net.out_ch, self.clamp) if pout else None)
+                        if y1 is not None:
+                            y1.record_stream(sb)                    # allocated on A, read (now and from temp2's FIFO) on B
+                        if y is not None:
+                            if not pout:
+                                y = ex.to_nchw(y, self.net.out_ch, self.clamp)
+                            y = y.to(out_dtype)
+                    if step < F + self.shift_num:
+                        outs.append(y)
+                cur.wait_stream(sa)
+                cur.wait_stream(sb)
+                kept = outs[self.shift_num:]
+                for y in kept:
+                    y.record_stream(cur)
+                return torch.cat(kept, dim=0)
+            finally:
+                pipe.clear()                   # also after an exception: never leave stale buffers behind
 
     # ---- clip forward (bsvd_arch.py:490-499) -----------------------------------------------------
     def forward(self, input, noise_map=None):

@@ -69,7 +69,11 @@ def test_davis_sized_clip_temporal_locality(precision):
     x = _sigma30_clip(T, H, W, 6)
     y = m.clip_forward(x)
     m.engine_mode = "stream"
+    assert m.stream_overlap                                            # temp1(t+1) || temp2(t) on two HIP streams (default)
     assert torch.equal(m(x[None])[0], y)
+    m.stream_overlap = False                                           # the plain one-stream loop over feedin_one_element
+    assert torch.equal(m(x[None])[0], y)
+    m.stream_overlap = True
     m.engine_mode = "clip"
     t0 = 60
     x2 = x.clone()
