@@ -574,11 +574,30 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
     float *sc = smem + wid * (32 * 36);
     auto finish = [&](auto epi_c, auto act_c) {
         constexpr int EPI = decltype(epi_c)::value, ACT = decltype(act_c)::value;
-        struct Item { bool live; int64_t opix; int n8, c8; };
+        struct Item { bool live; int64_t opix; int n8, c8; float *dst; };
+        // PLAIN / RESID: everything that depends on the lane is computed once; an item only adds compile-time multiples of
+        // the (wave-uniform) row stride -- every instruction of a finishing wave waits for a gap between the co-resident
+        // wave's MFMAs, so per-item 64-bit address arithmetic was a measurable part of the epilogue
+        const int l_ox = PREC == 1 ? ox0 + (lane >> 2) : ox0 + (li & 15);
+        const int l_oy = oy0 + 2 * C::MT * wm + (PREC == 1 ? 0 : (li >> 4));
+        const int l_ch = n0 + wn * (C::NT * 32) + (PREC == 1 ? 8 * q : 8 * lh);
+        const int64_t l_pix = (int64_t)l_oy * p.Wo + l_ox;
+        const int64_t rowstride = (int64_t)p.Wo * p.Cout;
+        float *const l_base = p.y + (int64_t)f * p.y_fs + l_pix * p.Cout +
+                              (PREC == 1 ? (l_ch >> 4) * 16 + ((l_ch >> 3) & 1) * 4 : l_ch);
         auto item_of = [&](int i) {          // i = ((mt * NT + nt) * 2 + s), compile-time after unrolling
             const int sidx = i & 1, nt = (i >> 1) % C::NT, mt = (i >> 1) / C::NT;
             int oy, ox;
             Item t;
+            if constexpr (EPI != BSVD_EPI_PS_ADD) {
+                const int row = 2 * mt + (PREC == 1 ? sidx : 0);             // rows below the lane's base row
+                const int chadd = nt * 32 + (PREC == 1 ? 0 : 16 * sidx);     // channels (= floats in both layouts) above l_ch
+                t.n8 = t.c8 = l_ch + chadd;
+                t.live = l_oy + row < p.Ho && l_ox < p.Wo && t.n8 < p.Cout;
+                t.opix = l_pix + (int64_t)row * p.Wo;
+                t.dst = l_base + row * rowstride + chadd;
+                return t;
+            }
             if constexpr (PREC == 1) {       // s = which 16 of the tile's 32 pixels; 4 adjacent lanes share a pixel
                 const int m = (lane + 64 * sidx) >> 2;
                 oy = oy0 + 2 * C::MT * wm + 2 * mt + (m >> 4);
@@ -594,9 +613,11 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 const int sub = t.n8 / Cq;
                 t.c8 = t.n8 - sub * Cq;                                      // first of 8 channels in the shuffled tensor
                 t.opix = (int64_t)(2 * oy + (sub >> 1)) * (2 * p.Wo) + (2 * ox + (sub & 1));
+                t.dst = p.y + (int64_t)f * p.y_fs + t.opix * Cq + (PREC == 1 ? (t.c8 >> 4) * 16 + ((t.c8 >> 3) & 1) * 4 : t.c8);
             } else {
                 t.c8 = t.n8;
                 t.opix = (int64_t)oy * p.Wo + ox;
+                t.dst = nullptr;     // (not reached: the fast path above returns first)
             }
             return t;
         };
@@ -675,9 +696,8 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                                 v[j] = p.extra[(int64_t)f * p.extra_fs + t.opix * p.extra_ps + (int64_t)j * p.extra_cs] - v[j];
                     }
                 }
-                const int cstride = EPI == BSVD_EPI_PS_ADD ? Cq : p.Cout;
                 if constexpr (PREC == 1) {
-                    float *dst = p.y + (int64_t)f * p.y_fs + t.opix * cstride + coff16(t.c8);
+                    float *dst = t.dst;
                     constexpr bool bounded = ACT == BSVD_ACT_RELU6 && EPI == BSVD_EPI_PLAIN;
                     f16x8 hi, lo;
 #pragma unroll
@@ -694,7 +714,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     *reinterpret_cast<f32x4 *>(dst + 8) = __builtin_bit_cast(f32x4, lo);
 #endif
                 } else {
-                    float *dst = p.y + (int64_t)f * p.y_fs + t.opix * cstride + t.c8;
+                    float *dst = t.dst;
                     *reinterpret_cast<f32x4 *>(dst) = f32x4{v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f32x4 *>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
                 }
