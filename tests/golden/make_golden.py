@@ -259,8 +259,10 @@ def g4b_bsvd_defaults(ref):
 def g5_bsvd_c64(ref):
     """The shipped config bsvd_c64 (options/test/bsvd_c64.yml:85-93): real channel counts, K up to 2304."""
     seed = 501
+    # "d": a clip LONGER than the 16-step pipeline latency (steady state of the buffers/FIFOs: data feeds and results
+    # overlap for 4 steps before the flush starts), tiny frames to keep the fixture small
     for tag, shape, kind in (("a", (1, 5, 4, 32, 48), "randn"), ("b", (1, 3, 4, 64, 96), "sigma30"),
-                             ("c", (1, 2, 4, 20, 36), "sigma30")):
+                             ("c", (1, 2, 4, 20, 36), "sigma30"), ("d", (1, 20, 4, 8, 12), "sigma30")):
         net = ref.BSVD(chns=[64, 128, 256], mid_ch=64, shift_input=False, in_ch=4, out_ch=3, norm="none",
                        act="relu6", interm_ch=64, blind=False, pretrain_ckpt=None)
         st = load_seeded(net, seed)

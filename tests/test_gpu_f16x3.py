@@ -108,7 +108,7 @@ def _module(st, mode="clip"):
     return m.to(_dev())
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_golden_c64_split(tag):
     g = load_golden("g5_bsvd_c64_" + tag)
     st = state_for(g, bsvd_keys([64, 128, 256], 64, 4, 3, 64))

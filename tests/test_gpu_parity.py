@@ -175,14 +175,14 @@ def test_golden_default_ctor_odd_channels():
     assert maxabs(y.cpu().numpy(), g["out"]) < TOL
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_golden_c64(tag):
     g = load_golden("g5_bsvd_c64_" + tag)
     st = state_for(g, bsvd_keys([64, 128, 256], 64, 4, 3, 64))
     m = _module([64, 128, 256], 64, 64, "relu6", st)
     y = m(torch.from_numpy(g["x"]).to(_dev()))
     assert maxabs(y.cpu().numpy(), g["out"]) < TOL
-    if tag == "c":
+    if tag in ("c", "d"):
         m.engine_mode = "stream"
         assert maxabs(m(torch.from_numpy(g["x"]).to(_dev())).cpu().numpy(), g["out"]) < TOL
 

@@ -97,7 +97,7 @@ def test_g4b_defaults_odd_channels():
     assert maxabs(y.numpy(), g["out"]) < TOL
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])     # d: 20 frames > the 16-step latency (pipeline steady state)
 def test_g5_bsvd_c64(tag):
     g = load_golden("g5_bsvd_c64_" + tag)
     st = state_for(g, bsvd_keys([64, 128, 256], 64, 4, 3, 64))
@@ -109,6 +109,7 @@ def test_g5_bsvd_c64(tag):
     if tag == "c":
         for name in ("t1_x0", "t1_x2", "t1_out"):
             assert maxabs(taps[name].numpy(), g[name]) < TOL, name
+    if tag in ("c", "d"):
         ys = O.stream_forward(x, P)
         assert maxabs(ys.numpy(), g["out"]) < TOL
 

@@ -95,13 +95,16 @@ def test_default_ctor_odd_channels():
     assert maxabs(y, g["out"]) < TOL
 
 
-@pytest.mark.parametrize("tag", ["a", "c"])
+@pytest.mark.parametrize("tag", ["a", "c", "d"])
 def test_c64_clip(tag):
     g = load_golden("g5_bsvd_c64_" + tag)
     st = state_for(g, bsvd_keys([64, 128, 256], 64, 4, 3, 64))
     net = make_netspec([64, 128, 256], 64, 4, 3, "relu6", 64)
     y, _ = run_clip(net, st, g["x"])
     assert maxabs(y, g["out"]) < TOL
+    if tag == "d":          # 20 frames: the stream schedule reaches its steady state (results while data still arrives)
+        ys, _ = run_stream(net, st, g["x"])
+        assert maxabs(ys, g["out"]) < TOL
 
 
 def test_blind_wnet_semantics_and_tsn_checkpoint_keys():
