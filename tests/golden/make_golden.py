@@ -256,6 +256,22 @@ def g4b_bsvd_defaults(ref):
     save("g4b_bsvd_defaults", x=x, out=t2n(y), seed=np.int64(seed), digest=np.array(state_digest(st)))
 
 
+def g4c_batch_is_one_clip(ref):
+    """N > 1: the reference reshapes [N,F,C,H,W] to N*F frames and streams them as ONE clip (bsvd_arch.py:494-499) --
+    frames of different batch items become temporal neighbours.  Recorded from the real forward, plus the proof that
+    it equals the 1 x (N*F) clip."""
+    seed = 461
+    net = ref.BSVD(chns=[32, 64, 128], mid_ch=32, shift_input=False, in_ch=4, out_ch=3, norm="none",
+                   act="relu6", interm_ch=32, blind=False, pretrain_ckpt=None)
+    st = load_seeded(net, seed)
+    x = seeded_clip((2, 3, 4, 12, 20), seed + 1)
+    with torch.no_grad():
+        y = net(torch.from_numpy(x))
+        y1 = net(torch.from_numpy(x.reshape(1, 6, 4, 12, 20)))
+    assert tuple(y.shape) == (2, 3, 3, 12, 20) and torch.equal(y.reshape(1, 6, 3, 12, 20), y1)
+    save("g4c_batch_is_one_clip", x=x, out=t2n(y), seed=np.int64(seed), digest=np.array(state_digest(st)))
+
+
 def g5_bsvd_c64(ref):
     """The shipped config bsvd_c64 (options/test/bsvd_c64.yml:85-93): real channel counts, K up to 2304."""
     seed = 501
@@ -467,6 +483,7 @@ def main():
     g3_denblock(ref)
     g4_bsvd_small(ref)
     g4b_bsvd_defaults(ref)
+    g4c_batch_is_one_clip(ref)
     g5_bsvd_c64(ref)
     g6_blind()
     g7_ckpt_keymap(ref)

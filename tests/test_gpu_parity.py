@@ -166,6 +166,16 @@ def test_golden_small_net(T):
     assert torch.equal(yc, ys), "clip and stream schedules run the same kernels on the same operands"
 
 
+def test_golden_batch_of_clips_is_one_long_clip():
+    """N = 2 (recorded from the real reference forward): frames of different batch items are temporal neighbours."""
+    g = load_golden("g4c_batch_is_one_clip")
+    st = state_for(g, bsvd_keys([32, 64, 128], 32, 4, 3, 32))
+    x = torch.from_numpy(g["x"]).to(_dev())
+    for mode in ("clip", "stream"):
+        y = _module([32, 64, 128], 32, 32, "relu6", st, mode=mode)(x)
+        assert tuple(y.shape) == g["out"].shape and maxabs(y.cpu().numpy(), g["out"]) < TOL
+
+
 def test_golden_default_ctor_odd_channels():
     g = load_golden("g4b_bsvd_defaults")
     st = state_for(g, bsvd_keys([32, 64, 128], 3, 4, 3, 30))

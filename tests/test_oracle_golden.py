@@ -69,6 +69,18 @@ def test_g3_denblock_taps(tag, in_ch, out_ch):
     assert maxabs(torch.cat(outs).numpy(), g["out"]) < TOL
 
 
+def test_g4c_batch_is_one_long_clip():
+    """N = 2: the reference streams the N*F frames as ONE clip (bsvd_arch.py:494-499); recorded from the real forward."""
+    g = load_golden("g4c_batch_is_one_clip")
+    st = state_for(g, bsvd_keys([32, 64, 128], 32, 4, 3, 32))
+    P = O.to_torch_state(st)
+    cfg = O.default_cfg(chns=[32, 64, 128], mid_ch=32, interm_ch=32)
+    x = torch.from_numpy(g["x"])
+    assert x.shape[0] == 2
+    assert maxabs(O.bsvd_clip(x, P, cfg).numpy(), g["out"]) < TOL
+    assert maxabs(O.stream_forward(x, P, cfg).numpy(), g["out"]) < TOL
+
+
 @pytest.mark.parametrize("T", [1, 2, 3, 7])
 def test_g4_bsvd_small(T):
     g = load_golden("g4_bsvd_small_T%d" % T)

@@ -62,6 +62,16 @@ def test_macs_and_shift_num_c64():
     assert abs(blind.macs_per_frame(540, 960) / 1e9 - 582.4) < 0.1
 
 
+def test_batch_of_clips_is_one_long_clip():
+    g = load_golden("g4c_batch_is_one_clip")
+    st = state_for(g, bsvd_keys([32, 64, 128], 32, 4, 3, 32))
+    net = make_netspec([32, 64, 128], 32, 4, 3, "relu6", 32)
+    y, _ = run_clip(net, st, g["x"])
+    assert y.shape == g["out"].shape and maxabs(y, g["out"]) < TOL
+    y, _ = run_stream(net, st, g["x"])
+    assert maxabs(y.reshape(g["out"].shape), g["out"]) < TOL
+
+
 @pytest.mark.parametrize("T", [1, 2, 3, 7])
 def test_small_net_clip_and_stream(T):
     g = load_golden("g4_bsvd_small_T%d" % T)
