@@ -193,8 +193,12 @@ class BSVD(_HipNet):
 
     # ---- streaming protocol (bsvd_arch.py:459-461, 485-488) --------------------------------------
     def reset(self):
+        """Starts a new stream.  Deliberate deviation: the reference's reset() clears only the BiBufferConv state
+        (bsvd_arch.py:459-461, 352-356); after an unfinished stream its MemSkip FIFOs keep stale frames and pair them
+        with every later clip, forever (golden g4d records it).  Here reset() empties the skip FIFOs too, so a reset
+        stream equals a fresh one and the stream schedule can never disagree with the clip schedule."""
         if self._pipe is not None:
-            self._pipe.reset()
+            self._pipe.clear()
 
     def feedin_one_element(self, x):
         """x: [1,C,H,W] tensor or None (flush).  Returns the frame fed ``shift_num`` steps earlier, or None."""

@@ -272,6 +272,28 @@ def g4c_batch_is_one_clip(ref):
     save("g4c_batch_is_one_clip", x=x, out=t2n(y), seed=np.int64(seed), digest=np.array(state_digest(st)))
 
 
+def g4d_reset_mid_stream(ref):
+    """Quirk: BSVD.reset() (bsvd_arch.py:459-461 -> DenBlock.reset :352-356) clears the BiBufferConv state only; the
+    MemSkip FIFOs keep whatever an unfinished stream left in them and pair it with the next stream's frames.  Recorded:
+    three frames fed frame by frame, reset() without a flush, then a whole 5-frame clip through forward()."""
+    seed = 471
+    net = ref.BSVD(chns=[32, 64, 128], mid_ch=32, shift_input=False, in_ch=4, out_ch=3, norm="none",
+                   act="relu6", interm_ch=32, blind=False, pretrain_ckpt=None)
+    st = load_seeded(net, seed)
+    pre = seeded_clip((1, 3, 4, 12, 20), seed + 1)
+    x = seeded_clip((1, 5, 4, 12, 20), seed + 2)
+    with torch.no_grad():
+        clean = net(torch.from_numpy(x))
+        for t in range(3):
+            assert net.feedin_one_element(torch.from_numpy(pre[0, t:t + 1])) is None
+        net.reset()
+        dirty = net(torch.from_numpy(x))
+        again = net(torch.from_numpy(x))          # forward() flushes fully: the next clip is clean again?
+    save("g4d_reset_mid_stream", pre=pre, x=x, clean=t2n(clean), dirty=t2n(dirty), again=t2n(again),
+         differs=np.array(not torch.equal(clean, dirty)), again_clean=np.array(bool(torch.equal(again, clean))),
+         seed=np.int64(seed), digest=np.array(state_digest(st)))
+
+
 def g5_bsvd_c64(ref):
     """The shipped config bsvd_c64 (options/test/bsvd_c64.yml:85-93): real channel counts, K up to 2304."""
     seed = 501
@@ -484,6 +506,7 @@ def main():
     g4_bsvd_small(ref)
     g4b_bsvd_defaults(ref)
     g4c_batch_is_one_clip(ref)
+    g4d_reset_mid_stream(ref)
     g5_bsvd_c64(ref)
     g6_blind()
     g7_ckpt_keymap(ref)

@@ -176,6 +176,24 @@ def test_golden_batch_of_clips_is_one_long_clip():
         assert tuple(y.shape) == g["out"].shape and maxabs(y.cpu().numpy(), g["out"]) < TOL
 
 
+@pytest.mark.parametrize("mode", ["clip", "stream"])
+def test_reset_after_an_unfinished_stream_gives_a_fresh_stream(mode):
+    """Deliberate deviation: in the reference, reset() after three un-flushed feeds leaves stale skip
+    frames behind and the next clips come out wrong (golden g4d: `dirty`, `again` != `clean`).  Here the same call
+    sequence returns the clean result in both schedules."""
+    g = load_golden("g4d_reset_mid_stream")
+    assert bool(g["differs"]) and not bool(g["again_clean"])           # what the real reference does
+    st = state_for(g, bsvd_keys([32, 64, 128], 32, 4, 3, 32))
+    m = _module([32, 64, 128], 32, 32, "relu6", st, mode=mode)
+    pre, x = torch.from_numpy(g["pre"]).to(_dev()), torch.from_numpy(g["x"]).to(_dev())
+    assert maxabs(m(x).cpu().numpy(), g["clean"]) < TOL
+    for t in range(3):
+        assert m.feedin_one_element(pre[0, t:t + 1]) is None
+    m.reset()
+    assert maxabs(m(x).cpu().numpy(), g["clean"]) < TOL
+    assert maxabs(m(x).cpu().numpy(), g["clean"]) < TOL
+
+
 def test_golden_default_ctor_odd_channels():
     g = load_golden("g4b_bsvd_defaults")
     st = state_for(g, bsvd_keys([32, 64, 128], 3, 4, 3, 30))

@@ -69,6 +69,17 @@ def test_g3_denblock_taps(tag, in_ch, out_ch):
     assert maxabs(torch.cat(outs).numpy(), g["out"]) < TOL
 
 
+def test_g4d_reference_reset_quirk_is_recorded():
+    """The oracle reproduces the clean result; the golden documents that the REAL reference, after reset() in the middle
+    of an un-flushed stream, does not (stale MemSkip entries) -- the product deliberately deviates (bsvd_amd.BSVD.reset)."""
+    g = load_golden("g4d_reset_mid_stream")
+    st = state_for(g, bsvd_keys([32, 64, 128], 32, 4, 3, 32))
+    cfg = O.default_cfg(chns=[32, 64, 128], mid_ch=32, interm_ch=32)
+    y = O.bsvd_clip(torch.from_numpy(g["x"]), O.to_torch_state(st), cfg)
+    assert maxabs(y.numpy(), g["clean"]) < TOL
+    assert bool(g["differs"]) and maxabs(g["dirty"], g["clean"]) > 1.0 and not bool(g["again_clean"])
+
+
 def test_g4c_batch_is_one_long_clip():
     """N = 2: the reference streams the N*F frames as ONE clip (bsvd_arch.py:494-499); recorded from the real forward."""
     g = load_golden("g4c_batch_is_one_clip")
