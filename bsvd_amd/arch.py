@@ -61,10 +61,11 @@ class _HipNet(nn.Module):
         if precision == "f16x3":
             # channel counts that are not multiples of 16 ride on zero padding channels (e.g. interm_ch = 30 of the blind
             # config); a temporal-fusion layer needs whole 16-channel chunks per temporal source: fold % 16 == 0
-            bad = [l.key for l in net.layers if l.tsm and l.fold % 16]
+            bad = [l.key for l in net.layers if l.tsm and l.fold % 16 and not (l.fold == 8 and l.cout_pad <= 64)]
             if bad or net.net_in_ch not in (3, 4) or net.out_ch > 4:
-                raise ValueError("precision='f16x3' needs fold % 16 == 0 in the temporal-fusion layers (chns[1:] multiples "
-                                 "of 128) and <= 4 input/output channels; offending layers: %s" % (bad[:3],))
+                raise ValueError("precision='f16x3' needs temporal-fusion layers with fold % 16 == 0 or 64 channels (fold 8), "
+                                 "i.e. chns[1:] = (64|128k, 128k) like the c64 and c32 networks, and <= 4 input/output "
+                                 "channels; offending layers: %s" % (bad[:3],))
         self._packed = None
         self._packed_sig = None
         self._exec = None
@@ -151,7 +152,7 @@ class BSVD(_HipNet):
                     same results, bit for bit).
       precision   : 'fp32' (default; exact fp32 MFMA, bitwise an fmaf chain) or 'f16x3' (split-fp16 3-pass MFMA with
                     fp32 accumulation: fp32-class accuracy -- 2-4e-5 max-abs on bsvd_c64, budget 1e-3 -- at several
-                    times the throughput).  'f16x3' needs chns[1:] multiples of 128 (fold % 16 == 0).
+                    times the throughput).  'f16x3' needs 64-channel or 128k-channel temporal-fusion layers (fold 8 or fold % 16 == 0).
     """
 
     def __init__(self, chns=[32, 64, 128], mid_ch=3, shift_input=False, in_ch=4, out_ch=3, norm='bn', act='relu',

@@ -142,6 +142,22 @@ __global__ void halo_pack_kernel(const float *__restrict__ frame, float *__restr
     }
 }
 
+// split16 half-chunk slice (fold == 8): channels [c0, c0+8) of a split16 frame are two 16-byte pieces of one chunk
+// (hi at chunk*16 + half*4 floats, lo 8 floats further); the compact slice stores them as [hi x8 | lo x8] per pixel
+__global__ void halo_pack_split8_kernel(const float *__restrict__ frame, float *__restrict__ dst, int64_t HW, int C, int c0,
+                                        int unpack)
+{
+    const int off = (c0 >> 4) * 16 + ((c0 >> 3) & 1) * 4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < 2 * HW; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i >> 1;
+        const int part = (int)(i & 1);                       // 0 = hi, 1 = lo
+        float *f = const_cast<float *>(frame) + pix * C + off + part * 8;
+        float *d = dst + pix * 8 + part * 4;
+        if (unpack) *reinterpret_cast<float4 *>(f) = *reinterpret_cast<const float4 *>(d);
+        else *reinterpret_cast<float4 *>(d) = *reinterpret_cast<const float4 *>(f);
+    }
+}
+
 __global__ void halo_unpack_kernel(const float *__restrict__ src, float *__restrict__ frame, int64_t total, int C, int c0,
                                    int n)
 {
@@ -354,8 +370,14 @@ int bsvd_planar_to_u8(const float *src, uint8_t *dst, int32_t frames, int32_t C,
 int bsvd_halo_pack(const void *frame, void *dst, int32_t HW, int32_t C, int32_t c0, int32_t n, int32_t dtype,
                    void *stream)
 {
-    if (dtype != BSVD_F32) { set_error("bsvd_halo_pack: dtype %d not supported", dtype); return -2; }
+    if (dtype != BSVD_F32 && dtype != BSVD_F16X3) { set_error("bsvd_halo_pack: dtype %d not supported", dtype); return -2; }
     if (!frame || !dst || HW <= 0 || C <= 0 || c0 < 0 || n <= 0 || c0 + n > C) { set_error("bsvd_halo_pack: bad arguments"); return -3; }
+    if (dtype == BSVD_F16X3) {         // half-chunk slice of a split16 frame (whole chunks are plain float ranges: use BSVD_F32)
+        if (n != 8 || (c0 & 7) || (C & 15)) { set_error("bsvd_halo_pack: BSVD_F16X3 packs one 8-channel half chunk (n == 8, c0 %% 8 == 0)"); return -3; }
+        hipLaunchKernelGGL(halo_pack_split8_kernel, dim3(grid_for(2 * (int64_t)HW, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)frame, (float *)dst, (int64_t)HW, C, c0, 0);
+        return (int)hipGetLastError();
+    }
     const int64_t total = (int64_t)HW * n;
     hipLaunchKernelGGL(halo_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float *)frame, (float *)dst, total, C, c0, n);
@@ -365,8 +387,14 @@ int bsvd_halo_pack(const void *frame, void *dst, int32_t HW, int32_t C, int32_t 
 int bsvd_halo_unpack(const void *src, void *frame, int32_t HW, int32_t C, int32_t c0, int32_t n, int32_t dtype,
                      void *stream)
 {
-    if (dtype != BSVD_F32) { set_error("bsvd_halo_unpack: dtype %d not supported", dtype); return -2; }
+    if (dtype != BSVD_F32 && dtype != BSVD_F16X3) { set_error("bsvd_halo_unpack: dtype %d not supported", dtype); return -2; }
     if (!frame || !src || HW <= 0 || C <= 0 || c0 < 0 || n <= 0 || c0 + n > C) { set_error("bsvd_halo_unpack: bad arguments"); return -3; }
+    if (dtype == BSVD_F16X3) {
+        if (n != 8 || (c0 & 7) || (C & 15)) { set_error("bsvd_halo_unpack: BSVD_F16X3 unpacks one 8-channel half chunk (n == 8, c0 %% 8 == 0)"); return -3; }
+        hipLaunchKernelGGL(halo_pack_split8_kernel, dim3(grid_for(2 * (int64_t)HW, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)frame, const_cast<float *>((const float *)src), (int64_t)HW, C, c0, 1);
+        return (int)hipGetLastError();
+    }
     const int64_t total = (int64_t)HW * n;
     hipLaunchKernelGGL(halo_unpack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float *)src, (float *)frame, total, C, c0, n);

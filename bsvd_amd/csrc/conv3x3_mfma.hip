@@ -183,6 +183,13 @@ struct ChunkSrc {          // wave-uniform description of one 16-channel chunk's
     __amdgpu_buffer_rsrc_t rs;
     unsigned ps4;          // pixel stride in bytes
     unsigned soff;         // byte offset of the chunk's first channel inside a pixel
+    // fold == 8 (64-channel temporal-fusion layers of the c32-sized networks): chunk 0 is MIXED -- its channels 0..7 come
+    // from the next frame (rs/ps4/soff above), channels 8..15 from the previous frame (the second source below); each
+    // staging lane carries one 16-byte piece and picks its source by the 8-channel half the piece belongs to
+    bool mixed;
+    __amdgpu_buffer_rsrc_t rs2;
+    unsigned ps4_2, soff2;
+    bool compact1, compact2;   // the source is a compact [H][W][8-channel] slice (split16: [hi x8 | lo x8]), not a full frame
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -223,7 +230,7 @@ __device__ __forceinline__ void tl_stamp(int slot, int k)
 #else
 #define TL(k)
 #endif
-template <class C, bool FAST, int PREC>
+template <class C, bool FAST, int PREC, bool MIXF = false>
 __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -318,9 +325,24 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         const __amdgpu_buffer_rsrc_t rs_prev = make_rsrc(s.prev ? s.prev : s.cur, s.prev ? hw * s.prev_ps * 4u : 0u);
         const __amdgpu_buffer_rsrc_t rs_next = make_rsrc(s.next ? s.next : s.cur, s.next ? hw * s.next_ps * 4u : 0u);
         const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)p.Cin * 9u * p.Cout * 4u);
+        constexpr bool MIX = MIXF;     // separate instantiation (fold == 8): the mixed-chunk staging costs the plain one 6 %
         auto chunk_src = [&](int cb) {
             ChunkSrc c;
+            c.mixed = false;
             const int c0 = cb * 16;
+            if constexpr (MIX) {
+                if (p.fold == 8 && cb == 0) {
+                    c.mixed = true;
+                    c.compact1 = s.next_ps == 8; c.compact2 = s.prev_ps == 8;
+                    c.rs = rs_next; c.ps4 = s.next_ps * 4u;
+                    c.rs2 = rs_prev; c.ps4_2 = s.prev_ps * 4u;
+                    // fp32: channel c of a source sits at float offset co + (c - first channel of the slice); split16: the
+                    // pieces of a full frame keep their place inside chunk 0 (the channel offset co is not a byte offset)
+                    c.soff = PREC == 1 ? 0u : (unsigned)s.next_co * 4u;
+                    c.soff2 = PREC == 1 ? 0u : (unsigned)s.prev_co * 4u;
+                    return c;
+                }
+            }
             if (c0 < p.fold)          { c.rs = rs_next; c.ps4 = s.next_ps * 4u; c.soff = (s.next_co + c0) * 4u; }
             else if (c0 < 2 * p.fold) { c.rs = rs_prev; c.ps4 = s.prev_ps * 4u; c.soff = (s.prev_co + c0 - p.fold) * 4u; }
             else                      { c.rs = rs_cur;  c.ps4 = p.Cin * 4u;     c.soff = c0 * 4u; }
@@ -356,6 +378,25 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 const int prow = row0 + i * C::R + r3;
                 const int gy = iy0 + prow;
                 const bool ok = x_ok && prow < C::PH && gy >= 0 && gy < p.H;
+                if constexpr (MIX) {
+                    if (c.mixed) {
+                        const unsigned pix = (unsigned)(gy * p.W + gx);
+                        f32x4 a, b;
+                        if constexpr (PREC == 1) {       // pieces: 0 = hi 0..7, 1 = hi 8..15, 2 = lo 0..7, 3 = lo 8..15
+                            const bool second = pq & 1;
+                            const unsigned o1 = c.compact1 ? (pq >> 1) * 16u : pq * 16u, o2 = c.compact2 ? (pq >> 1) * 16u : pq * 16u;
+                            a = buf_load4(c.rs, ok && !second ? pix * c.ps4 + o1 : BSVD_OOB, c.soff);
+                            b = buf_load4(c.rs2, ok && second ? pix * c.ps4_2 + o2 : BSVD_OOB, c.soff2);
+                            v[i] = second ? b : a;
+                        } else {                         // quads: 0,1 = channels 0..7 (next), 2,3 = channels 8..15 (previous)
+                            const bool second = pq >> 1;
+                            a = buf_load4(c.rs, ok && !second ? pix * c.ps4 + pq * 16u : BSVD_OOB, c.soff);
+                            b = buf_load4(c.rs2, ok && second ? pix * c.ps4_2 + (pq - 2) * 16u : BSVD_OOB, c.soff2);
+                            v[i] = second ? b : a;
+                        }
+                        continue;
+                    }
+                }
                 const unsigned voff = ok ? (unsigned)(gy * p.W + gx) * c.ps4 + pq * 16u : BSVD_OOB;
                 v[i] = buf_load4(c.rs, voff, c.soff);
             }
@@ -736,12 +777,12 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
     TL(3);
 }
 
-template <class C, bool FAST, int PREC>
+template <class C, bool FAST, int PREC, bool MIXF = false>
 static int launch_cfg(const ConvParams &pin, hipStream_t stream, char *name = nullptr, int name_len = 0)
 {
     if (name) {      // dry run: report the instantiation bsvd_conv3x3 would launch (used by bench.py's per-kernel timing)
         snprintf(name, name_len, "conv3x3_kernel<%d,%d,%d,%d,%d>[%s]%s%s", C::MT, C::NT, C::WM, C::WN, C::STRIDE,
-                 PREC == 1 ? "f16x3" : "f32", FAST ? "" : "[generic]", pin.y_planar_ch > 0 ? "[planar out]" : "");
+                 PREC == 1 ? "f16x3" : "f32", FAST ? (MIXF ? "[fold8]" : "") : "[generic]", pin.y_planar_ch > 0 ? "[planar out]" : "");
         return 0;
     }
     ConvParams p = pin;
@@ -753,9 +794,9 @@ static int launch_cfg(const ConvParams &pin, hipStream_t stream, char *name = nu
     const int64_t nblk = (int64_t)p.frames * p.nty * p.ntx * p.nct;
     if (nblk <= 0 || nblk > 0x7fffffff) { set_error("bsvd_conv3x3: grid of %lld workgroups", (long long)nblk); return -1; }
     static std::atomic<int> granted[MAX_DEVICES];
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv3x3_kernel<C, FAST, PREC>), C::LDS_BYTES, granted);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv3x3_kernel<C, FAST, PREC, MIXF>), C::LDS_BYTES, granted);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((conv3x3_kernel<C, FAST, PREC>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv3x3_kernel<C, FAST, PREC, MIXF>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -763,14 +804,18 @@ static bool fast_ok(const ConvParams &p, bool honour_force_generic = true)
 {
     // FAST needs: 16-B aligned vector gather (vec_ok), single-source 16-channel chunks (fold % 16 == 0) and
     // 32-bit byte offsets inside one frame / the packed weights.  (ablate == 8: timing builds force GENERIC.)
-    return p.vec_ok && (p.fold & 15) == 0 && (int64_t)p.H * p.W * p.Cin * 4 < 0x7fffffffLL &&
+    const bool fold_ok = (p.fold & 15) == 0 || (p.fold == 8 && p.Cout <= 64);     // fold 8: mixed chunk 0 in the 64-channel tile
+    return p.vec_ok && fold_ok && (int64_t)p.H * p.W * p.Cin * 4 < 0x7fffffffLL &&
            (int64_t)p.Cin * 9 * p.Cout * 4 < 0x7fffffffLL && !(honour_force_generic && p.ablate == 8);
 }
 
 template <class C>
 static int launch_f32(const ConvParams &p, hipStream_t stream, char *name, int name_len)
 {
-    return fast_ok(p) ? launch_cfg<C, true, 0>(p, stream, name, name_len) : launch_cfg<C, false, 0>(p, stream, name, name_len);
+    if (!fast_ok(p)) return launch_cfg<C, false, 0>(p, stream, name, name_len);
+    if constexpr (C::STRIDE == 1 && C::BN == 64)
+        if (p.fold == 8) return launch_cfg<C, true, 0, true>(p, stream, name, name_len);
+    return launch_cfg<C, true, 0>(p, stream, name, name_len);
 }
 
 int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *name, int name_len)
@@ -781,7 +826,7 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
         // waves/SIMD the same tile needs > 256 registers and spills in the main loop: 10x slower.  <4,1,2,2,1,3> for
         // the 64-channel layers: no gain over <2,2,4,1,1,3>.)  Stride 2: single patch buffer -> 3 workgroups/CU
         // instead of 1 (175 -> 287 TFLOP/s).
-        if (!fast_ok(p, false)) { set_error("bsvd_conv3x3: BSVD_F16X3 needs fold %% 16 == 0 and 16-byte aligned operands"); return -17; }
+        if (!fast_ok(p, false)) { set_error("bsvd_conv3x3: BSVD_F16X3 needs fold %% 16 == 0 (or fold 8 with Cout <= 64) and 16-byte aligned operands"); return -17; }
 #ifndef BSVD_TUNE_S2_SPLIT
 #define BSVD_TUNE_S2_SPLIT 0       // 0: 8x16-px tile, single patch buffer; 1: 4x16-px tile, double-buffered
 #endif
@@ -799,6 +844,7 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
         if (p.Cout > 64)
             return fat_wide >= BSVD_TUNE_FAT_MIN_WGS ? launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len)
                                     : launch_cfg<ConvCfg<2, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
+        if (p.fold == 8) return launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1, true>(p, stream, name, name_len);   // c32-sized nets
         return launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1>(p, stream, name, name_len);   // (512-px fat tiles were tried: 9.6 vs 6.8 ms)
     }
     // exact fp32.  Cout <= 64 (the 540x960-level layers of bsvd_c64): 256 px x 64 ch tiles; wider layers: 128 px x 128 ch.

@@ -102,7 +102,9 @@ class HipExecutor:
         """compact [H,W,n] copy of channels [c0,c0+n) of one NHWC frame [H,W,C] (message to a neighbour shard)"""
         H, W, C = frame.shape[-3:]
         out = torch.empty((H, W, n), dtype=torch.float32, device=frame.device)
-        rc = self.lib.bsvd_halo_pack(frame.data_ptr(), out.data_ptr(), H * W, C, c0, n, _lib.BSVD_F32, _stream_ptr())
+        # split16: whole 16-channel chunks are plain float ranges; an 8-channel half chunk (fold 8) is two pieces
+        dt = _lib.BSVD_F16X3 if (self.split and (n % 16 or c0 % 16)) else _lib.BSVD_F32
+        rc = self.lib.bsvd_halo_pack(frame.data_ptr(), out.data_ptr(), H * W, C, c0, n, dt, _stream_ptr())
         _lib.check(rc, "bsvd_halo_pack")
         self.launches += 1
         return out
@@ -113,7 +115,8 @@ class HipExecutor:
         n = slice_.shape[-1]
         if not (frame.is_contiguous() and slice_.is_contiguous()):
             raise ValueError("halo_unpack: tensors must be contiguous")
-        rc = self.lib.bsvd_halo_unpack(slice_.data_ptr(), frame.data_ptr(), H * W, C, c0, n, _lib.BSVD_F32, _stream_ptr())
+        dt = _lib.BSVD_F16X3 if (self.split and (n % 16 or c0 % 16)) else _lib.BSVD_F32
+        rc = self.lib.bsvd_halo_unpack(slice_.data_ptr(), frame.data_ptr(), H * W, C, c0, n, dt, _stream_ptr())
         _lib.check(rc, "bsvd_halo_unpack")
         self.launches += 1
         return frame

@@ -156,7 +156,9 @@ int bsvd_planar_to_u8(const float *src, uint8_t *dst, int32_t frames, int32_t C,
  * Frame-window sharding: gathers the channel slice [c0, c0+n) of one NHWC frame into
  * a compact [H*W][n] buffer -- the message a rank sends to its temporal neighbour
  * (first frame, c0 = 0 -> the left neighbour's halo_next; last frame, c0 = fold -> the right
- * neighbour's halo_prev).
+ * neighbour's halo_prev).  dtype BSVD_F32: a plain float range (also right for WHOLE 16-channel chunks of a split16 frame);
+ * dtype BSVD_F16X3: one 8-channel half chunk of a split16 frame (n == 8, c0 % 8 == 0; the fold-8 layers of the c32-sized
+ * networks) -> dst [H*W][hi x8 | lo x8], which bsvd_conv3x3 reads as a compact halo (pstride = 8, coff = 0).
  */
 int bsvd_halo_pack(const void *frame, void *dst, int32_t HW, int32_t C, int32_t c0, int32_t n,
                    int32_t dtype, void *stream);

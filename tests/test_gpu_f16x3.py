@@ -19,9 +19,11 @@ def _dev():
 
 
 def to_split(x):
-    """fp32 NHWC [..., C] -> split16 container: per 16-channel chunk [hi x16 | lo x16] fp16 in the same 64 bytes."""
+    """fp32 NHWC [..., C] -> split16 container: per 16-channel chunk [hi x16 | lo x16] fp16 in the same 64 bytes.
+    (C == 8: a compact half-chunk slice, [hi x8 | lo x8] -- the halo of a fold-8 layer.)"""
     *lead, C = x.shape
-    v = x.reshape(*lead, C // 16, 16)
+    G = 16 if C % 16 == 0 else 8
+    v = x.reshape(*lead, C // G, G)
     hi = v.half()
     lo = (v - hi.float()).half()
     return torch.cat([hi, lo], dim=-1).contiguous().view(torch.float32).reshape(*lead, C)
@@ -29,8 +31,9 @@ def to_split(x):
 
 def from_split(s):
     *lead, C = s.shape
-    h = s.contiguous().view(torch.float16).reshape(*lead, C // 16, 32)
-    return (h[..., :16].float() + h[..., 16:].float()).reshape(*lead, C)
+    G = 16 if C % 16 == 0 else 8
+    h = s.contiguous().view(torch.float16).reshape(*lead, C // G, 2 * G)
+    return (h[..., :G].float() + h[..., G:].float()).reshape(*lead, C)
 
 
 def test_split_codec_roundtrip():
@@ -55,6 +58,8 @@ CASES = [
     # cin, cout, stride, tsm, act, epi, T, H, W
     (64, 64, 1, False, "relu6", 0, 1, 33, 50),
     (128, 128, 1, True, "relu6", 0, 3, 10, 19),
+    (64, 64, 1, True, "relu6", 0, 3, 10, 19),      # fold 8 (c32-sized networks): chunk 0 has two temporal sources
+    (64, 64, 1, True, "relu", 0, 1, 21, 36),       # ... single frame: both sources are halos
     (256, 256, 1, True, "relu", 0, 2, 9, 17),
     (64, 128, 2, False, "relu6", 0, 2, 20, 36),
     (128, 256, 2, False, "relu6", 0, 1, 27, 43),
@@ -91,6 +96,8 @@ def test_layer_split_vs_oracle(cin, cout, stride, tsm, act, epi, T, H, W):
         hp = from_split(to_split(torch.from_numpy(rs.standard_normal((H, W, fold)).astype(np.float32))))
         hn = from_split(to_split(torch.from_numpy(rs.standard_normal((H, W, fold)).astype(np.float32))))
         halos.append((Halo(hp, fold, 0), Halo(hn, fold, 0)))
+        full = from_split(to_split(torch.from_numpy(rs.standard_normal((1, H, W, cin)).astype(np.float32))))
+        halos.append((Halo(full, cin, fold), Halo(full, cin, 0)))          # full neighbour frames (stream schedule)
     for hp, hn in halos:
         want = oex.conv(sp, xq, hp, hn, extra, eps, ecs)
         d = lambda h: None if h is None else Halo(to_split(h.t).to(_dev()), h.pstride, h.coff)
@@ -136,5 +143,85 @@ def test_full_resolution_split_vs_oracle_and_fp32_path():
 
 def test_split_mode_rejects_unsupported_nets():
     import bsvd_amd
-    with pytest.raises(ValueError):
-        bsvd_amd.BSVD(chns=[32, 64, 128], mid_ch=32, norm="none", interm_ch=32, pretrain_ckpt=None, precision="f16x3")
+    with pytest.raises(ValueError):      # 96-channel temporal-fusion layers: fold 12
+        bsvd_amd.BSVD(chns=[32, 96, 128], mid_ch=32, norm="none", interm_ch=32, pretrain_ckpt=None, precision="f16x3")
+    with pytest.raises(ValueError):      # 192 channels: fold 24 is neither a whole chunk nor the half chunk of a 64-channel layer
+        bsvd_amd.BSVD(chns=[64, 192, 256], mid_ch=32, norm="none", interm_ch=32, pretrain_ckpt=None, precision="f16x3")
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 7])
+def test_golden_c32_sized_net_split(T):
+    """chns = [32, 64, 128] (the c32-sized network; goldens g4 from the real reference): its 64-channel temporal-fusion
+    layers have fold 8 -- half a 16-channel chunk per temporal source -- and run on the mixed-chunk instantiation."""
+    import bsvd_amd
+    g = load_golden("g4_bsvd_small_T%d" % T)
+    st = state_for(g, bsvd_keys([32, 64, 128], 32, 4, 3, 32))
+    x = torch.from_numpy(g["x"]).to(_dev())
+    outs = {}
+    for mode in ("clip", "stream"):
+        m = bsvd_amd.BSVD(chns=[32, 64, 128], mid_ch=32, in_ch=4, out_ch=3, norm="none", act="relu6", interm_ch=32,
+                          pretrain_ckpt=None, engine_mode=mode, precision="f16x3")
+        m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
+        outs[mode] = m.to(_dev())(x)
+        err = maxabs(outs[mode].cpu().numpy(), g["out"])
+        print("g4 T=%d c32-sized f16x3 %s max-abs vs reference golden: %.3e" % (T, mode, err))
+        assert err < TIGHT
+    assert torch.equal(outs["clip"], outs["stream"])
+
+
+def test_c32_sized_sharded_equals_unsharded_split():
+    """fold-8 layers exchange compact half-chunk slices ([hi x8 | lo x8], bsvd_halo_pack dtype BSVD_F16X3)."""
+    import bsvd_amd
+    from bsvd_amd.schedule import Halo
+    from bsvd_amd.dist import shard_range
+    import threading
+    g = load_golden("g4_bsvd_small_T7")
+    st = state_for(g, bsvd_keys([32, 64, 128], 32, 4, 3, 32))
+    x = torch.from_numpy(g["x"][0]).to(_dev())
+
+    def model():
+        m = bsvd_amd.BSVD(chns=[32, 64, 128], mid_ch=32, in_ch=4, out_ch=3, norm="none", act="relu6", interm_ch=32,
+                          pretrain_ckpt=None, precision="f16x3")
+        m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
+        return m.to(_dev())
+
+    whole = model().clip_forward(x)
+    world, boxes, results, errors = 2, {}, [None, None], []
+    barrier = threading.Barrier(world)
+
+    def rank(r):
+        try:
+            torch.cuda.set_device(0)
+            m = model()
+            ex = m._executor(_dev())
+
+            class TH:
+                def start(self, sp, v):
+                    fold = sp.fold
+                    boxes[(r, sp.key)] = (ex.halo_pack(v[0], 0, fold), ex.halo_pack(v[-1], fold, fold))
+
+                    class P:
+                        def finish(self_p):
+                            torch.cuda.synchronize()
+                            barrier.wait()
+                            other = boxes[(1 - r, sp.key)]
+                            barrier.wait()
+                            return (None, Halo(other[0], fold, 0)) if r == 0 else (Halo(other[1], fold, 0), None)
+                    return P()
+
+                def __call__(self, sp, v):
+                    return self.start(sp, v).finish()
+
+            a, b = shard_range(7, world, r)
+            results[r] = m.clip_forward(x[a:b], TH())
+            torch.cuda.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+            barrier.abort()
+
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    assert torch.equal(torch.cat(results), whole)
+    assert maxabs(whole.cpu().numpy(), g["out"][0]) < TIGHT

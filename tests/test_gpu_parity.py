@@ -46,6 +46,8 @@ LAYER_CASES = [
     (4, 64, 1, False, "relu6", 0, 2, 20, 36),       # first layer: Cin padded 4 -> 16
     (64, 64, 1, False, "relu6", 0, 1, 33, 50),      # 256px x 64ch tile config, ragged edges
     (128, 128, 1, True, "relu6", 0, 3, 10, 19),     # temporal shift, fold 16, odd sizes
+    (64, 64, 1, True, "relu6", 0, 3, 10, 19),       # fold 8: mixed first chunk on the fast path (c32-sized networks)
+    (64, 64, 1, True, "relu", 0, 1, 21, 36),        # ... single frame, both halos
     (256, 256, 1, True, "relu", 0, 4, 9, 17),       # fold 32, K = 2304, 2 cout tiles
     (64, 128, 2, False, "relu6", 0, 2, 20, 36),     # stride 2
     (128, 256, 2, False, "relu6", 0, 1, 27, 43),    # stride 2, odd input size
