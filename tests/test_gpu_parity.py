@@ -196,13 +196,22 @@ def test_reset_after_an_unfinished_stream_gives_a_fresh_stream(mode):
     assert maxabs(m(x).cpu().numpy(), g["clean"]) < TOL
 
 
-def test_golden_default_ctor_odd_channels():
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_golden_default_ctor_odd_channels(precision):
+    """The reference constructor's own defaults (chns [32,64,128], mid_ch 3, interm_ch 30, ReLU) with norm='none'."""
+    import bsvd_amd
     g = load_golden("g4b_bsvd_defaults")
     st = state_for(g, bsvd_keys([32, 64, 128], 3, 4, 3, 30))
     x = torch.from_numpy(g["x"]).to(_dev())
-    m = _module([32, 64, 128], 3, 30, "relu", st)
+    m = bsvd_amd.BSVD(norm="none", pretrain_ckpt=None, precision=precision)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
+    m = m.to(_dev())
     y = m(x[:, :, :3], noise_map=x[:, :, 3:4])
-    assert maxabs(y.cpu().numpy(), g["out"]) < TOL
+    err = maxabs(y.cpu().numpy(), g["out"])
+    print("reference-default ctor, %s: max-abs vs golden %.2e" % (precision, err))
+    assert err < (TOL if precision == "fp32" else 3e-4)
+    m.engine_mode = "stream"
+    assert torch.equal(m(x[:, :, :3], noise_map=x[:, :, 3:4]), y)
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
