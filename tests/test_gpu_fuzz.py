@@ -45,7 +45,7 @@ def test_random_layer_split_fp16(seed):
     S.test_layer_split_vs_oracle(*args)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(15))
 def test_random_clip_whole_network(seed):
     """bsvd_c64 on random small clips (any T >= 1, H and W multiples of 4 from 4 to 48): clip schedule vs the CPU oracle
     in both arithmetic modes, stream schedule bit-identical, blind variant on odd seeds."""
@@ -57,20 +57,21 @@ def test_random_clip_whole_network(seed):
     rs = np.random.RandomState(3000 + seed)
     T, H, W = int(rs.randint(1, 6)), 4 * int(rs.randint(1, 13)), 4 * int(rs.randint(1, 13))
     blind = bool(seed & 1)
-    interm, act, cin = (30, "relu", 3) if blind else (64, "relu6", 4)
-    st = seeded_state(bsvd_keys([64, 128, 256], 64, 4, 3, interm, blind=blind), 40 + seed)
+    chns, mid = ([64, 128, 256], 64) if seed % 3 else ([32, 64, 128], 32)       # every third case: the c32-sized network
+    interm, act, cin = (30, "relu", 3) if blind else (chns[0], "relu6", 4)
+    st = seeded_state(bsvd_keys(chns, mid, 4, 3, interm, blind=blind), 40 + seed)
     x = torch.from_numpy(rs.standard_normal((1, T, cin, H, W)).astype(np.float32))
-    cfg = O.default_cfg(act=act, interm_ch=interm, blind=blind)
+    cfg = O.default_cfg(chns=chns, mid_ch=mid, act=act, interm_ch=interm, blind=blind)
     want = O.bsvd_clip(x, O.to_torch_state(st), cfg)
     dev = torch.device("cuda", 0)
     for precision in ("fp32", "f16x3"):
-        m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, in_ch=4, out_ch=3, norm="none", act=act, interm_ch=interm,
+        m = bsvd_amd.BSVD(chns=chns, mid_ch=mid, in_ch=4, out_ch=3, norm="none", act=act, interm_ch=interm,
                           blind=blind, pretrain_ckpt=None, precision=precision)
         m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
         m = m.to(dev)
         y = m(x.to(dev))
         err = maxabs(y.cpu().numpy(), want.numpy())
-        print("T=%d %dx%d blind=%s %s max-abs %.2e" % (T, H, W, blind, precision, err))
+        print("T=%d %dx%d chns=%s blind=%s %s max-abs %.2e" % (T, H, W, chns, blind, precision, err))
         assert err < 1e-3
         m.engine_mode = "stream"
         assert torch.equal(m(x.to(dev)), y)
