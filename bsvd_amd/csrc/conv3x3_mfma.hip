@@ -271,7 +271,8 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
     // The weights are the MFMA's A operand (rows = output channels) and the pixels its B operand (columns), so a lane ends
     // up holding 16 output channels of ONE pixel: D row of register r is (r&3) + 8*(r>>2) + 4*lh.  Row i is fed with
     // channel chan(i) such that registers 0..7 / 8..15 of a lane are 8 consecutive channels each (groups 2h + lh):
-    // the epilogue then stores 16-byte pieces straight from registers, no transposition through LDS.
+    // the exact-fp32 epilogue then stores 16-byte pieces straight from registers, and the split one stages a tile into its
+    // transposition scratch with four ds_write_b128 per lane.
     const int rrow = (li & 3) + 4 * (li >> 3);                   // register index that holds row li (in lane half (li>>2)&1)
     const int chan = 8 * (2 * (rrow >> 3) + ((li >> 2) & 1)) + (rrow & 7);
     const int nb0 = n0 + wn * (C::NT * 32) + chan;               // output channel whose weights this lane loads for nt = 0 (+32 per nt)
