@@ -2,20 +2,21 @@
 //
 //   y[f] = epilogue( act( conv3x3( gather(x[f-1], x[f], x[f+1], fold) ) + bias ) )
 //
-// GEMM view per frame: M = Ho*Wo output pixels, N = Cout, K = 9*Cin, on v_mfma_f32_32x32x2_f32
-// (f32 in / f32 accumulate, bitwise an fmaf chain, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak).
+// GEMM view per frame: pixels x Cout x (9*Cin), on v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate, bitwise an fmaf
+// chain, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak).  The WEIGHTS are the MFMA's A operand (rows = output channels) and
+// the pixels its B operand, so a lane ends up with 16 output channels of one pixel (see `chan` below and the epilogue).
 //
-// Workgroup = 4 waves (256 threads), output tile = (TH x 16) pixels x BN channels.  Each wave owns a
-// 64-pixel (4 rows x 16 cols) x 64-channel sub-tile = 2x2 MFMA tiles = 64 accumulator VGPRs.
-// K is walked as (channel chunk of 16) x (9 taps), 32 MFMAs per wave per (chunk, tap) step:
-//   * A operand: per channel chunk the input patch incl. the 1-pixel halo is staged ONCE in LDS and reused
+// Workgroup = 4 waves (256 threads), output tile = (TH x 16) pixels x BN channels.  Each wave owns MT x NT 32x32 MFMA
+// tiles: 64 px x 64 ch (2x2, 64 accumulators, 3 waves/SIMD) or 128 px x 64 ch (4x2, 128 accumulators, 2 waves/SIMD:
+// the wide split-fp16 layers).  K is walked as (channel chunk of 16) x (9 taps):
+//   * pixel operand: per channel chunk the input patch incl. the 1-pixel halo is staged ONCE in LDS and reused
 //     by all 9 taps and all BN output channels; the temporal-shift gather is folded into this staging
 //     load as a source select (no torch.cat copy).  The next chunk's patch is prefetched in row slices
-//     during the taps of the current chunk (double-buffered LDS, one barrier per chunk = 288 MFMAs).
-//   * B operand: weights go straight from global/L2 to VGPRs in the pre-packed [k4][Cout][4] layout
-//     (lanes = consecutive output channels -> coalesced 512-B runs); no LDS round trip, no per-tap barrier.
+//     during the taps of the current chunk (double-buffered LDS, one barrier per chunk).
+//   * weight operand: straight from global/L2 to VGPRs in the pre-packed [k4][Cout][4] layout; no LDS round trip, no
+//     per-tap barrier.
 //
-// FAST path (fold % 16 == 0, 16-B aligned operands; every bsvd_c64 layer): each 16-channel chunk has a
+// FAST path (fold % 16 == 0 -- or fold 8 on the [fold8] instantiation --, 16-B aligned operands): each 16-channel chunk has a
 // single temporal source, so all global reads are branch-free raw buffer loads (out-of-range lanes read 0
 // = zero padding / masking for free) and the weight fragments run TWO steps ahead in a 3-deep register
 // ring, the patch slices two steps ahead in a second ring.  Measured on MI355X the memory latency seen by a
@@ -32,9 +33,9 @@
 // the SAME 64 bytes the fp32 layout uses, weights are pre-split the same way, and each K=16 block issues three
 // v_mfma_f32_32x32x16_f16 (hi*hi + lo*hi + hi*lo, fp32 accumulate; the lo*lo term is ~2^-22 relative and dropped).
 // 16x the MFMA rate of the fp32 instruction for 3x the instructions; measured max-abs error vs the fp32 reference
-// 2-4e-5 on bsvd_c64 (same class as the exact path; plain fp16 gives 1-3e-2).  The epilogue transposes each
-// 32x32 accumulator tile through a wave-private LDS scratch so that every lane stores 8 channels of one pixel as
-// two 16-byte vectors (hi, lo).
+// 2-4e-5 on bsvd_c64 (same class as the exact path; plain fp16 gives 1-3e-2).  The split epilogue passes each
+// 32x32 accumulator tile through a wave-private LDS scratch so that 4 ADJACENT lanes store the 4 x 8 channels of one
+// pixel (128 contiguous bytes) as 16-byte vectors (hi, lo); the exact-fp32 epilogue stores from registers.
 //
 // Reference ops replaced: see include/bsvd_hip.h (bsvd_conv3x3).
 #include <stdio.h>
