@@ -165,9 +165,12 @@ def calculate_ssim(img, img2, crop_border, input_order='HWC', test_y_channel=Fal
 METRICS = {"calculate_psnr": calculate_psnr, "calculate_psnr_float": calculate_psnr_float, "calculate_ssim": calculate_ssim}
 
 
-def evaluate(model, dataset, metrics_opt):
+def evaluate(model, dataset, metrics_opt, per_frame=None, save_img_dir=None, run_name="bsvd"):
     """model: bsvd_amd.DenoisingModel; metrics_opt: {name: {type: calculate_psnr, crop_border: 2}, ...} as in
-    options/test/bsvd_c64.yml:116-123.  Returns ({folder: {metric: mean}}, {metric: mean over folders})."""
+    options/test/bsvd_c64.yml:116-123.  Returns ({folder: {metric: mean}}, {metric: mean over folders}).
+    per_frame (a dict) receives {folder: {metric: [value per frame]}} -- what the reference writes to one CSV per folder
+    (denoising_model.py:335-345); save_img_dir writes the denoised frames as <dir>/<folder>/<idx:08d>_<run_name>.png
+    (uint8 BGR->RGB, the reference's save_img naming, :295-299)."""
     per_folder = {}
     for i in range(len(dataset)):
         item = dataset[i]
@@ -185,5 +188,13 @@ def evaluate(model, dataset, metrics_opt):
                 else:
                     acc[name].append(fn(tensor2img(res[f]), tensor2img(gt[f]), **mo))
         per_folder[item['folder']] = {k: float(np.mean(v)) for k, v in acc.items()}
+        if per_frame is not None:
+            per_frame[item['folder']] = acc
+        if save_img_dir is not None:
+            from PIL import Image
+            d = os.path.join(save_img_dir, item['folder'])
+            os.makedirs(d, exist_ok=True)
+            for f in range(res.shape[0]):
+                Image.fromarray(tensor2img(res[f], rgb2bgr=False)).save(os.path.join(d, "%08d_%s.png" % (f, run_name)))
     total = {k: float(np.mean([v[k] for v in per_folder.values()])) for k in metrics_opt} if per_folder else {}
     return per_folder, total

@@ -56,10 +56,19 @@ def test_run_test_counterpart_end_to_end(tmp_path):
                                "ssim": {"type": "calculate_ssim", "crop_border": 2, "test_y_channel": False}}}}
     yml = tmp_path / "opt.yml"
     yml.write_text(yaml.safe_dump(opt))
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_test.py"), "-opt", str(yml)],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_test.py"), "-opt", str(yml),
+                          "--csv_dir", str(tmp_path / "csv"), "--save_img", str(tmp_path / "vis")],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads(out.stdout[out.stdout.index("{\n"):])["syn30"]
+    # the reference's per-dataset log line, per-folder per-frame CSV (denoising_model.py:335-359) and save_img naming (:299)
+    assert "Validation syn30\n\t # psnr: %.4f" % res["mean"]["psnr"] in out.stdout
+    rows = (tmp_path / "csv" / "syn30_clipA.csv").read_text().strip().splitlines()
+    assert rows[0] == ",clipA_0,clipA_1,clipA_2" and len(rows) == 1 + 5
+    assert abs(np.mean([float(r.split(",")[1]) for r in rows[1:]]) - res["folders"]["clipA"]["psnr"]) < 1e-4
+    shots = sorted(os.listdir(tmp_path / "vis" / "syn30" / "clipB"))
+    assert shots == ["%08d_t.png" % i for i in range(4)]
+    assert np.asarray(Image.open(tmp_path / "vis" / "syn30" / "clipB" / shots[0])).shape == (30, 50, 3)
     # oracle pipeline with the same RNG stream: seed -> model construction (consumes RNG) -> per-clip noise in sorted order
     import bsvd_amd
     torch.manual_seed(10)

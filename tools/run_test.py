@@ -28,6 +28,10 @@ def main():
     ap.add_argument("-opt", required=True)
     ap.add_argument("--precision", default=None, choices=["fp32", "f16x3"])
     ap.add_argument("--force_yml", nargs="+", default=None, help="key:sub=value overrides")
+    ap.add_argument("--csv_dir", default=None, help="write one <dataset>_<folder>.csv of per-frame metrics per folder, columns "
+                                                    "<folder>_<metric index> like the reference (denoising_model.py:335-345)")
+    ap.add_argument("--save_img", default=None, metavar="DIR", help="write the denoised frames as "
+                                                                    "DIR/<dataset>/<folder>/<idx:08d>_<name>.png (val.save_img)")
     args = ap.parse_args()
     opt = yaml.safe_load(open(args.opt))
     for item in args.force_yml or []:
@@ -59,9 +63,24 @@ def main():
             print("skip %s: %s does not exist" % (dopt.get("name", key), dopt["valsetdir"]))
             continue
         ds = evaluation.ValFolderDataset(dopt)
-        per_folder, total = evaluation.evaluate(model, ds, metrics)
-        results[dopt.get("name", key)] = {"folders": per_folder, "mean": total}
-        print("%s: %s" % (dopt.get("name", key), json.dumps(total)))
+        dname = dopt.get("name", key)
+        per_frame = {}
+        per_folder, total = evaluation.evaluate(model, ds, metrics, per_frame=per_frame, run_name=opt.get("name", "bsvd"),
+                                                save_img_dir=os.path.join(args.save_img, dname) if args.save_img else None)
+        results[dname] = {"folders": per_folder, "mean": total}
+        # the reference's log line (denoising_model.py:353-359)
+        log = "Validation %s\n" % dname
+        for mi, (metric, value) in enumerate(total.items()):
+            log += "\t # %s: %.4f" % (metric, value) + "".join("\t # %s: %.4f" % (f, v[metric]) for f, v in per_folder.items()) + "\n"
+        print(log, end="")
+        if args.csv_dir:
+            os.makedirs(args.csv_dir, exist_ok=True)
+            for folder, acc in per_frame.items():
+                with open(os.path.join(args.csv_dir, "%s_%s.csv" % (dname, folder)), "w") as fh:
+                    cols = list(acc)
+                    fh.write("," + ",".join("%s_%d" % (folder, i) for i in range(len(cols))) + "\n")
+                    for r in range(len(acc[cols[0]])):
+                        fh.write("%d," % r + ",".join(repr(float(acc[c][r])) for c in cols) + "\n")
     print(json.dumps(results, indent=1))
 
 
