@@ -19,6 +19,9 @@ ap.add_argument("--half", action="store_true", help="net_g.half() + autocast lik
 ap.add_argument("--mode", default="clip", choices=["clip", "stream"])
 ap.add_argument("--repeat", type=int, default=10)
 ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"])
+ap.add_argument("--trace", default=None, metavar="FILE.json",
+                help="also record one forward with torch.profiler (the reference's 'torchprofile19' mode, scripts/profiler.py:85-101) "
+                     "and export a chrome trace; the hand-written kernels show up under their own names")
 args = ap.parse_args()
 
 name = "BSVD" if "BSVD" in bsvd_amd.ARCH_REGISTRY else "BSVD_MI355X"
@@ -41,3 +44,10 @@ with torch.no_grad():
         best = min(best, time.perf_counter() - t0)
 print("%d loops, mean of best 1: %.6f sec per loop  (%.1f frames/s)" % (args.repeat, best, args.frames / best))
 print("max memory required \t\t %.2fGB" % (torch.cuda.max_memory_allocated() / 1024 ** 3))
+if args.trace:
+    from torch.profiler import ProfilerActivity, profile
+    with torch.no_grad(), profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        net(inp)
+        torch.cuda.synchronize()
+    prof.export_chrome_trace(args.trace)
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=8))
