@@ -257,7 +257,7 @@ class BSVD(_HipNet):
             if self._pipe is None:
                 self._pipe = StreamPipeline(self.net)
             pipe = self._pipe
-            if self._ab_streams is None:
+            if self._ab_streams is None or self._ab_streams[0].device != dev:      # (re)created if the module moved
                 self._ab_streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
             sa, sb = self._ab_streams
             cur = torch.cuda.current_stream(dev)
