@@ -847,6 +847,10 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
             return fat_wide >= BSVD_TUNE_FAT_MIN_WGS ? launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len)
                                     : launch_cfg<ConvCfg<2, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
         if (p.fold == 8) return launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1, true>(p, stream, name, name_len);   // c32-sized nets
+#ifndef BSVD_TUNE_NARROW_ALT
+#define BSVD_TUNE_NARROW_ALT 0     // 1: 128-px x 32-ch wave tiles (<4,1,2,2>) for the 64-channel layers instead of 64 x 64
+#endif
+        if (BSVD_TUNE_NARROW_ALT) return launch_cfg<ConvCfg<4, 1, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
         return launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1>(p, stream, name, name_len);   // (512-px fat tiles were tried: 9.6 vs 6.8 ms)
     }
     // exact fp32.  Cout <= 64 (the 540x960-level layers of bsvd_c64): 256 px x 64 ch tiles; wider layers: 128 px x 128 ch.
