@@ -9,14 +9,15 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BSVD_HIP_LIB") or os.path.join(_HERE, "libbsvd_hip.so")   # env override: A/B tuning builds
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 BSVD_F32, BSVD_F16, BSVD_F16X3 = 0, 1, 2
 ACT = {"none": 0, "relu": 1, "relu6": 2}
 EPI_PLAIN, EPI_PS_ADD, EPI_RESID = 0, 1, 2
 
 EXPORTS = ("bsvd_abi_version", "bsvd_conv_args_size", "bsvd_last_error", "bsvd_conv3x3", "bsvd_conv3x3_variant", "bsvd_packed_weight_elems", "bsvd_pack_weights",
            "bsvd_nchw_to_nhwc", "bsvd_nhwc_to_nchw", "bsvd_halo_pack", "bsvd_halo_unpack", "bsvd_workspace_bytes",
-           "bsvd_u8_to_planar", "bsvd_planar_to_u8")
+           "bsvd_u8_to_planar", "bsvd_planar_to_u8", "bsvd_conv3x3_batch", "bsvd_graph_begin", "bsvd_graph_fork",
+           "bsvd_graph_join", "bsvd_graph_end", "bsvd_graph_abort", "bsvd_graph_launch", "bsvd_graph_destroy")
 
 
 class BsvdConvArgs(ctypes.Structure):
@@ -92,6 +93,13 @@ def load():
     lib.bsvd_halo_pack.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     lib.bsvd_halo_unpack.restype = ctypes.c_int
     lib.bsvd_halo_unpack.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.bsvd_conv3x3_batch.restype = ctypes.c_int
+    lib.bsvd_conv3x3_batch.argtypes = [ctypes.POINTER(BsvdConvArgs), i32, vp]
+    for fn, at in (("bsvd_graph_begin", [vp]), ("bsvd_graph_fork", [vp, vp]), ("bsvd_graph_join", [vp, vp]),
+                   ("bsvd_graph_end", [vp, ctypes.POINTER(vp), ctypes.POINTER(i32)]), ("bsvd_graph_abort", [vp]),
+                   ("bsvd_graph_launch", [vp, vp]), ("bsvd_graph_destroy", [vp])):
+        getattr(lib, fn).restype = ctypes.c_int
+        getattr(lib, fn).argtypes = at
     lib.bsvd_workspace_bytes.restype = i64
     lib.bsvd_workspace_bytes.argtypes = [ctypes.POINTER(BsvdConvArgs)]
     if lib.bsvd_abi_version() != ABI_VERSION:

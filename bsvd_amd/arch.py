@@ -148,8 +148,12 @@ class BSVD(_HipNet):
                     the clip's activations fit the free HBM, else 'stream').  Same function, bit-identical results.
       clamp       : optional (lo, hi) fused into the exit kernel (callers clamp to [0,1] anyway,
                     validation_seq_infer.py:24).
-      stream_overlap : streaming_forward runs the two DenBlocks of consecutive steps on two HIP streams (default True;
-                    same results, bit for bit).
+      stream_overlap : streaming_forward runs DenBlock 1 of step k and DenBlock 2 of step k-1 as two parallel branches of
+                    one HIP graph (default True; same results, bit for bit).
+      stream_rings / stream_graphs : the stream schedule runs on preallocated ring buffers and replays each step as a
+                    HIP graph (both default True; False = the allocating layer-by-layer path / batched launches).
+      stream_chunk : frames per pipeline step of streaming_forward ('auto': up to 8 as memory allows; 1 = the reference's
+                    frame-by-frame pipeline).  feedin_one_element always runs one frame per step.
       precision   : 'fp32' (default; exact fp32 MFMA, bitwise an fmaf chain) or 'f16x3' (split-fp16 3-pass MFMA with
                     fp32 accumulation: fp32-class accuracy -- 2-4e-5 max-abs on bsvd_c64, budget 1e-3 -- at several
                     times the throughput).  'f16x3' needs 64-channel or 128k-channel temporal-fusion layers (fold 8 or fold % 16 == 0).
@@ -157,7 +161,8 @@ class BSVD(_HipNet):
 
     def __init__(self, chns=[32, 64, 128], mid_ch=3, shift_input=False, in_ch=4, out_ch=3, norm='bn', act='relu',
                  interm_ch=30, blind=False, pretrain_ckpt='./experiments/pretrained_ckpt/bsvd-64.pth',
-                 engine_mode='auto', clamp=None, precision='fp32', stream_overlap=True):
+                 engine_mode='auto', clamp=None, precision='fp32', stream_overlap=True, stream_rings=True,
+                 stream_graphs=True, stream_chunk='auto'):
         super().__init__()
         if shift_input:
             raise NotImplementedError("shift_input=True (CvBlock input stage) is not used by any BSVD config; "
@@ -170,8 +175,11 @@ class BSVD(_HipNet):
         self._init_engine(make_netspec(chns, mid_ch, in_ch, out_ch, act, interm_ch, blind), precision, clamp)
         self.engine_mode = engine_mode
         self.last_mode = None          # schedule the last forward() actually ran ('clip' | 'stream')
-        self.stream_overlap = bool(stream_overlap)   # streaming_forward: temp1(t+1) and temp2(t) on two HIP streams
-        self._ab_streams = None
+        self.stream_overlap = bool(stream_overlap)   # streaming_forward: temp1(step k) and temp2(step k-1) as parallel graph branches
+        self.stream_rings = bool(stream_rings)       # stream schedule on preallocated rings (False: allocate per layer)
+        self.stream_graphs = bool(stream_graphs)     # ... replayed as HIP graphs (False: one batched launch call per step)
+        self.stream_chunk = stream_chunk             # streaming_forward: frames per pipeline step ('auto' | int)
+        self._stream_engs, self._stream_key = {}, None
         # Same RNG consumption as the reference constructor (each DenBlock re-initialises itself, then BSVD does it
         # again, bsvd_arch.py:350,453): a seeded run draws the same weights AND leaves the generator in the same state,
         # so the evaluation noise that follows (ValFolderDataset) is the reference's realisation.
@@ -200,38 +208,102 @@ class BSVD(_HipNet):
         stream equals a fresh one and the stream schedule can never disagree with the clip schedule."""
         if self._pipe is not None:
             self._pipe.clear()
+        for eng in self._stream_engs.values():
+            eng.clear()
+
+    def release_stream_buffers(self):
+        """Frees the ring buffers and HIP graphs of the stream schedule (they are kept between calls otherwise)."""
+        for eng in self._stream_engs.values():
+            eng.release()
+        self._stream_engs, self._stream_key = {}, None
+
+    @property
+    def _stream_eng(self):
+        """the per-frame (chunk 1) ring engine, if it exists"""
+        return self._stream_engs.get(1)
+
+    def _stream_engine(self, ex, frame_shape, chunk=1):
+        """Ring/graph engine (stream_plan.StreamEngine) for frames shaped ``frame_shape`` = (C,H,W), ``chunk`` frames per
+        pipeline step; None if this network's edge layers cannot take planar frames (then the allocating StreamPipeline
+        runs)."""
+        pin, pout = planar_ok(ex, self.net)
+        if not (pin and pout and self.stream_rings):
+            return None
+        key = (id(ex), tuple(frame_shape), None if self.clamp is None else tuple(self.clamp), self.stream_graphs)
+        if self._stream_key != key:
+            if len(frame_shape) != 3 or frame_shape[0] != self.net.net_in_ch:
+                raise ValueError("expected frames [%d,H,W], got %s" % (self.net.net_in_ch, tuple(frame_shape)))
+            self.release_stream_buffers()
+            if self._pipe is not None:
+                self._pipe.clear()
+            self._stream_key = key
+        eng = self._stream_engs.get(chunk)
+        if eng is None:
+            from .stream_plan import StreamEngine
+            for other in [c for c in self._stream_engs if c != 1 and c != chunk]:     # keep the per-frame engine + one chunked
+                self._stream_engs.pop(other).release()
+            eng = self._stream_engs[chunk] = StreamEngine(self.net, ex, frame_shape[1], frame_shape[2], frame_shape[0],
+                                                          chunk=chunk, use_graphs=self.stream_graphs)
+        return eng
+
+    def _pick_chunk(self, F, H, W):
+        """Frames per pipeline step of streaming_forward: ``stream_chunk`` if given, else the largest of 8/4/2/1 whose rings
+        fit half of the free HBM (540x960: 9.7 GB per frame of chunk; 1080p: 39 GB)."""
+        if self.stream_chunk != "auto":
+            return max(1, min(int(self.stream_chunk), F))
+        from .stream_plan import ring_bytes_estimate
+        dev = self._device()
+        free, _ = torch.cuda.mem_get_info(dev)
+        free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        held = sum(e.ring_bytes for e in self._stream_engs.values())
+        for n in (8, 4, 2):
+            if n <= F and ring_bytes_estimate(self.net, H, W, n) <= 0.5 * (free + held):
+                return n
+        return 1
 
     def feedin_one_element(self, x):
-        """x: [1,C,H,W] tensor or None (flush).  Returns the frame fed ``shift_num`` steps earlier, or None."""
+        """x: [1,C,H,W] tensor or None (flush).  Returns the frame fed ``shift_num`` steps earlier, or None.
+        Runs on preallocated rings; a step whose launch pattern has been seen before is one HIP-graph replay."""
         dev = self._device()
         with torch.no_grad(), torch.cuda.device(dev):
             ex = self._executor(dev)
+            if x is not None:
+                self._last_dtype = x.dtype if x.dtype in (torch.float16, torch.bfloat16) else torch.float32
+            if x is not None and (x.dim() != 4 or x.shape[0] != 1):
+                raise ValueError("feedin_one_element expects one frame [1,C,H,W], got %s" % (tuple(x.shape),))
+            eng = self._stream_engine(ex, x.shape[1:]) if x is not None else self._stream_eng
+            if eng is not None or (x is None and self._pipe is None):
+                if eng is None:
+                    return None                  # flush before any frame: nothing is pending (like the reference)
+                y = eng.feed(x, (self.net.out_ch, self.clamp))        # a view of the exit ring: hand the caller a copy
+                return None if y is None else y.to(getattr(self, "_last_dtype", torch.float32), copy=True)
             if self._pipe is None:
                 self._pipe = StreamPipeline(self.net)
             xin = None
-            out_dtype = torch.float32
             pin, pout = planar_ok(ex, self.net)
             if x is not None:
-                out_dtype = x.dtype if x.dtype in (torch.float16, torch.bfloat16) else torch.float32
                 xin = x.to(device=dev, dtype=torch.float32).contiguous()
                 if not pin:
                     xin = ex.to_nhwc(xin, self.net.temp1["inc0"].cin_pad)
-                self._last_dtype = out_dtype
             y = self._pipe.feed(ex, xin, x_planar=pin, y_planar=(self.net.out_ch, self.clamp) if pout else None)
             if y is None:
                 return None
             if not pout:
                 y = ex.to_nchw(y, self.net.out_ch, self.clamp)
-            return y.to(getattr(self, "_last_dtype", out_dtype))
+            return y.to(getattr(self, "_last_dtype", torch.float32))
 
     def streaming_forward(self, input_seq):
         """Pipeline-style inference over a clip (bsvd_arch.py:501-552): F data feeds, then flush feeds until
-        F + shift_num results exist; the first shift_num (None) are dropped; state is reset afterwards."""
+        F + shift_num results exist; the first shift_num (None) are dropped; state is reset afterwards.
+        With the whole list in hand the engine runs the same pipeline on rings with ``stream_chunk`` frames per step and
+        (``stream_overlap``) DenBlock 2 one step behind DenBlock 1; bit-identical to the frame-by-frame loop."""
         if isinstance(input_seq, torch.Tensor):
             input_seq = [input_seq[i:i + 1] for i in np.arange(input_seq.shape[0])]
         assert type(input_seq) == list, "convert the input into a sequence"
-        if self.stream_overlap and len(input_seq) > 0:
-            return self._streaming_forward_overlapped(input_seq)
+        if len(input_seq) > 0:
+            out = self._streaming_forward_rings(input_seq)
+            if out is not None:
+                return out
         outs = []
         try:
             for x in input_seq:
@@ -240,62 +312,51 @@ class BSVD(_HipNet):
                 outs.append(self.feedin_one_element(None))
             self.feedin_one_element(None)      # the reference's extra, discarded flush call (:541-542)
         finally:
-            if self._pipe is not None:
-                self._pipe.clear()             # also after an exception: never leave stale buffers behind
+            self.reset()                       # also after an exception: never leave stale buffers behind
         return torch.cat(outs[self.shift_num:], dim=0)
 
-    def _streaming_forward_overlapped(self, input_seq):
-        """Same pipeline, same kernels, same results as the loop above, but the two DenBlocks of consecutive steps run on
-        two HIP streams: temp2 of step t (stream B) overlaps temp1 of step t+1 (stream A).  The frames=1 launches of the
-        quarter-resolution layers do not fill 256 CUs on their own; two independent launch queues do (+8 % measured with
-        two unrelated streams, tools/concurrent_streams.py).  Only possible here, where the whole list is in hand: the
-        per-frame API (feedin_one_element) must hand its result to the caller's stream before it returns."""
+    def _streaming_forward_rings(self, input_seq):
+        """The pipeline of the loop above on stream_plan.StreamEngine: n = ``stream_chunk`` consecutive frames per pipeline
+        step and, with ``stream_overlap``, temp1(step k) and temp2(step k-1) -- which do not depend on each other -- as two
+        parallel branches of one HIP graph.  The single-frame launches of the quarter-resolution layers do not fill 256 CUs
+        on their own; chunks and two independent chains do.  Only possible here: the per-frame API (feedin_one_element)
+        must return frame k-16 before it sees frame k+1."""
         dev = self._device()
         F = len(input_seq)
+        x0 = input_seq[0]
+        if x0.dim() != 4 or x0.shape[0] != 1:
+            raise ValueError("streaming_forward expects frames [1,C,H,W], got %s" % (tuple(x0.shape),))
         with torch.no_grad(), torch.cuda.device(dev):
             ex = self._executor(dev)
-            if self._pipe is None:
-                self._pipe = StreamPipeline(self.net)
-            pipe = self._pipe
-            if self._ab_streams is None or self._ab_streams[0].device != dev:      # (re)created if the module moved
-                self._ab_streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
-            sa, sb = self._ab_streams
-            cur = torch.cuda.current_stream(dev)
             pin, pout = planar_ok(ex, self.net)
-            out_dtype = input_seq[0].dtype if input_seq[0].dtype in (torch.float16, torch.bfloat16) else torch.float32
-            sa.wait_stream(cur)
-            sb.wait_stream(cur)
-            outs = []
+            if not (pin and pout and self.stream_rings):
+                return None
+            n = self._pick_chunk(F, x0.shape[-2], x0.shape[-1])
+            eng = self._stream_engine(ex, x0.shape[1:], n)
+            out_dtype = x0.dtype if x0.dtype in (torch.float16, torch.bfloat16) else torch.float32
+            ypl = (self.net.out_ch, self.clamp)
+            out = torch.empty((F, self.net.out_ch) + tuple(x0.shape[-2:]), dtype=out_dtype, device=dev)
+            chunks = [input_seq[i:i + n] for i in range(0, F, n)]
+            steps = len(chunks) + self.shift_num + 1                 # incl. the reference's extra, discarded flush call
+            eng.clear()
+            pos = 0
             try:
-                for step in range(F + self.shift_num + 1):           # incl. the reference's extra, discarded flush call
-                    x = input_seq[step] if step < F else None
-                    with torch.cuda.stream(sa):
-                        xin = None
-                        if x is not None:
-                            xin = x.to(device=dev, dtype=torch.float32).contiguous()
-                            xin.record_stream(sa)                   # may alias the caller's tensor; kept in temp1's FIFO
-                            if not pin:
-                                xin = ex.to_nhwc(xin, self.net.temp1["inc0"].cin_pad)
-                        y1 = pipe.t1.feed(ex, xin, x_planar=pin)
-                    sb.wait_stream(sa)                              # everything of temp1(step); temp1(step+1) comes later
-                    with torch.cuda.stream(sb):
-                        y = pipe.t2.feed(ex, y1, y_planar=(self.net.out_ch, self.clamp) if pout else None)
-                        if y1 is not None:
-                            y1.record_stream(sb)                    # allocated on A, read (now and from temp2's FIFO) on B
-                        if y is not None:
-                            if not pout:
-                                y = ex.to_nchw(y, self.net.out_ch, self.clamp)
-                            y = y.to(out_dtype)
-                    if step < F + self.shift_num:
-                        outs.append(y)
-                cur.wait_stream(sa)
-                cur.wait_stream(sb)
-                kept = outs[self.shift_num:]
-                for y in kept:
-                    y.record_stream(cur)
-                return torch.cat(kept, dim=0)
+                if self.stream_overlap:
+                    for k in range(steps + 1):                       # step k issues temp1(k) and temp2(k-1)
+                        y = eng.feed_lagged(chunks[k] if k < len(chunks) else None, ypl, last=k == steps)
+                        if y is not None and pos < F:
+                            out[pos:pos + y.shape[0]].copy_(y)
+                            pos += y.shape[0]
+                else:
+                    for k in range(steps):
+                        y = eng.feed(chunks[k] if k < len(chunks) else None, ypl)
+                        if y is not None and pos < F:
+                            out[pos:pos + y.shape[0]].copy_(y)
+                            pos += y.shape[0]
+                assert pos == F, (pos, F)
+                return out
             finally:
-                pipe.clear()                   # also after an exception: never leave stale buffers behind
+                eng.clear()
 
     # ---- clip forward (bsvd_arch.py:490-499) -----------------------------------------------------
     def forward(self, input, noise_map=None):

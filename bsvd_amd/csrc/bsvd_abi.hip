@@ -408,4 +408,94 @@ int64_t bsvd_workspace_bytes(const BsvdConvArgs *args)
     return rc < 0 ? (int64_t)rc : 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// one streaming step as one submission: batch launch + HIP graph capture / replay
+int bsvd_conv3x3_batch(const BsvdConvArgs *args, int32_t n, void *stream)
+{
+    if (n < 0 || (n > 0 && !args)) { set_error("bsvd_conv3x3_batch: bad arguments"); return -1; }
+    for (int32_t i = 0; i < n; ++i) {
+        const int rc = conv3x3_impl(args + i, stream, nullptr, 0);
+        if (rc != 0) {
+            if (rc < 0) {
+                char msg[400];
+                snprintf(msg, sizeof(msg), "%s", g_err);
+                set_error("bsvd_conv3x3_batch: layer %d of %d: %s", i, n, msg);
+            }
+            return rc;
+        }
+    }
+    return 0;
+}
+
+int bsvd_graph_begin(void *capture_stream)
+{
+    if (!capture_stream) { set_error("bsvd_graph_begin: the default stream cannot be captured; pass a created stream"); return -1; }
+    return (int)hipStreamBeginCapture((hipStream_t)capture_stream, hipStreamCaptureModeRelaxed);
+}
+
+static int graph_edge(hipStream_t from, hipStream_t to)
+{
+    hipEvent_t ev;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return (int)e;
+    e = hipEventRecord(ev, from);
+    if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
+    (void)hipEventDestroy(ev);      // the dependency edge lives in the capturing graph, not in the event
+    return (int)e;
+}
+
+int bsvd_graph_fork(void *capture_stream, void *side_stream)
+{
+    if (!capture_stream || !side_stream) { set_error("bsvd_graph_fork: NULL stream"); return -1; }
+    return graph_edge((hipStream_t)capture_stream, (hipStream_t)side_stream);
+}
+
+int bsvd_graph_join(void *capture_stream, void *side_stream)
+{
+    if (!capture_stream || !side_stream) { set_error("bsvd_graph_join: NULL stream"); return -1; }
+    return graph_edge((hipStream_t)side_stream, (hipStream_t)capture_stream);
+}
+
+int bsvd_graph_end(void *capture_stream, void **graph_exec, int32_t *num_nodes)
+{
+    if (!capture_stream || !graph_exec) { set_error("bsvd_graph_end: NULL argument"); return -1; }
+    *graph_exec = nullptr;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture((hipStream_t)capture_stream, &g);
+    if (e != hipSuccess || !g) return e != hipSuccess ? (int)e : (int)hipErrorUnknown;
+    if (num_nodes) {
+        size_t n = 0;
+        (void)hipGraphGetNodes(g, nullptr, &n);
+        *num_nodes = (int32_t)n;
+    }
+    hipGraphExec_t ex = nullptr;
+    e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return (int)e;
+    *graph_exec = ex;
+    return 0;
+}
+
+int bsvd_graph_abort(void *capture_stream)
+{
+    if (!capture_stream) return -1;
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture((hipStream_t)capture_stream, &g);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    return 0;
+}
+
+int bsvd_graph_launch(void *graph_exec, void *stream)
+{
+    if (!graph_exec) { set_error("bsvd_graph_launch: NULL graph"); return -1; }
+    return (int)hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
+}
+
+int bsvd_graph_destroy(void *graph_exec)
+{
+    if (!graph_exec) return 0;
+    return (int)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+}
+
 }  // extern "C"

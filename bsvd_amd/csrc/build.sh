@@ -1,18 +1,21 @@
 #!/bin/bash
 # Builds libbsvd_hip.so for gfx950 in-tree (bsvd_amd/libbsvd_hip.so).  hipcc cross-compiles without a GPU.
+# Objects are rebuilt when a source / header is newer OR when the compile flags (EXTRA_HIPCC_FLAGS tuning defines
+# included) differ from the ones the object was built with (recorded next to it in <obj>.flags).
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function ${EXTRA_HIPCC_FLAGS}"
 OUT="${BSVD_OUT:-$ROOT/bsvd_amd/libbsvd_hip.so}"
 OBJ="$HERE/obj${BSVD_OBJ_SUFFIX:-}"
 mkdir -p "$OBJ"
 pids=()
 for src in conv3x3_mfma conv3x3_edge_f32 bsvd_abi; do
   if [ ! -f "$OBJ/$src.o" ] || [ "$HERE/$src.hip" -nt "$OBJ/$src.o" ] || \
-     [ "$HERE/bsvd_internal.h" -nt "$OBJ/$src.o" ] || [ "$ROOT/include/bsvd_hip.h" -nt "$OBJ/$src.o" ]; then
-    $HIPCC $FLAGS ${EXTRA_HIPCC_FLAGS} -c "$HERE/$src.hip" -o "$OBJ/$src.o" &
+     [ "$HERE/bsvd_internal.h" -nt "$OBJ/$src.o" ] || [ "$ROOT/include/bsvd_hip.h" -nt "$OBJ/$src.o" ] || \
+     [ "$(cat "$OBJ/$src.flags" 2>/dev/null)" != "$FLAGS" ]; then
+    ( $HIPCC $FLAGS -c "$HERE/$src.hip" -o "$OBJ/$src.o" && echo "$FLAGS" > "$OBJ/$src.flags" ) &
     pids+=($!)
   fi
 done

@@ -39,6 +39,7 @@
 //
 // Reference ops replaced: see include/bsvd_hip.h (bsvd_conv3x3).
 #include <stdio.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "bsvd_internal.h"
 
@@ -195,7 +196,7 @@ struct ChunkSrc {          // wave-uniform description of one 16-channel chunk's
 
 // ------------------------------------------------------------------------------------------------------
 #ifndef BSVD_TUNE_FAT_MIN_WGS
-#define BSVD_TUNE_FAT_MIN_WGS 1024  // smallest grid (in 256-px x 128-ch workgroups) that takes the fat split tile
+#define BSVD_TUNE_FAT_MIN_WGS 800   // smallest grid (in 256-px x 128-ch workgroups) that takes the fat split tile (r02: 1020-workgroup launches -- 256-ch layers of a 1080p frame, upc1 of a 540x960 frame -- are 1-3 % faster fat; 510-540 are not)
 #endif
 #ifndef BSVD_TUNE_S2F32_OCC
 #define BSVD_TUNE_S2F32_OCC 2      // waves/SIMD the exact-fp32 stride-2 kernel is compiled for (3 = 168 VGPRs + a 20-B spill: 2.3 % slower)
@@ -843,8 +844,9 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
         // The fat tiles run one workgroup per CU, so they need a grid of several rounds of 256; small launches
         // (streaming mode: one frame per launch) keep the 64x64 tiles at 3 workgroups per CU.
         const int64_t fat_wide = (int64_t)p.frames * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16) * ((p.Cout + 127) / 128);
+        static const int fat_min = [] { const char *e = getenv("BSVD_FAT_MIN_WGS"); return e ? atoi(e) : BSVD_TUNE_FAT_MIN_WGS; }();   // tuning override
         if (p.Cout > 64)
-            return fat_wide >= BSVD_TUNE_FAT_MIN_WGS ? launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len)
+            return fat_wide >= fat_min ? launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len)
                                     : launch_cfg<ConvCfg<2, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
         if (p.fold == 8) return launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1, true>(p, stream, name, name_len);   // c32-sized nets
 #ifndef BSVD_TUNE_NARROW_ALT

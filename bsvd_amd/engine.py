@@ -55,8 +55,10 @@ class PackedNet:
                                            wp.data_ptr(), bp.data_ptr(), _stream_ptr())
                 _lib.check(rc, "bsvd_pack_weights(%s)" % sp.key)
                 self.tensors[sp.key] = (wp, bp)
-            # w/b temporaries are consumed by kernels queued on the current stream; the caching allocator
-            # keeps stream order, so letting them go out of scope here is safe.
+            # The packed tensors are read from whatever stream a later forward runs on (ClipPipeline's compute stream,
+            # the A/B streams of streaming_forward, a graph replay): finish the one-time pack here so no consumer can see
+            # half-packed weights.  (The w/b temporaries are consumed by kernels queued on this stream.)
+            torch.cuda.current_stream(device).synchronize()
 
 
 class HipExecutor:
@@ -137,6 +139,24 @@ class HipExecutor:
         """x_planar: x is the caller's planar [T,C,H,W] tensor (first layer).  y_planar=(channels, clamp|None):
         write the planar [T,channels,H,W] result directly (last layer).  out: optional preallocated (contiguous,
         e.g. a frame range of a larger tensor) destination instead of a fresh allocation."""
+        a, y = self.build_args(sp, x, halo_prev, halo_next, extra, extra_pstride, extra_cstride, x_planar, y_planar, out)
+        if self.record_variants:
+            buf = ctypes.create_string_buffer(96)
+            _lib.check(self.lib.bsvd_conv3x3_variant(ctypes.byref(a), buf, 96), "bsvd_conv3x3_variant(%s)" % sp.key)
+            self.last_variant = buf.value.decode()
+        rc = self.lib.bsvd_conv3x3(ctypes.byref(a), _stream_ptr())
+        _lib.check(rc, "bsvd_conv3x3(%s)" % sp.key)
+        self.launches += 1
+        return y
+
+    @staticmethod
+    def lib_args_type():
+        return _lib.BsvdConvArgs
+
+    def build_args(self, sp, x, halo_prev=None, halo_next=None, extra=None, extra_pstride=0, extra_cstride=1,
+                   x_planar=False, y_planar=None, out=None, alloc=True):
+        """Validates one fused layer and fills its ``BsvdConvArgs``; returns (args, y).  ``alloc=False`` leaves ``y`` (and
+        ``args.y``) unset for the caller to supply per launch (the stream plan's exit layer)."""
         a = _lib.BsvdConvArgs()
         if not x.is_contiguous():
             raise ValueError("%s: input must be contiguous" % sp.key)
@@ -161,18 +181,22 @@ class HipExecutor:
             yc, clamp = y_planar
             if sp.cout_pad != 16 or yc != sp.cout or sp.stride != 1 or sp.tsm or sp.epilogue == EPI_PS_ADD:
                 raise ValueError("%s: planar output needs a plain stride-1 layer with <= 4 output channels" % sp.key)
-            y = torch.empty((T, yc, H, W), dtype=torch.float32, device=x.device)
+            yshape = (T, yc, H, W)
             a.y_planar_ch = yc
             if clamp is not None:
                 a.y_clamp, a.y_lo, a.y_hi = 1, float(clamp[0]), float(clamp[1])
         elif sp.epilogue == EPI_PS_ADD:
-            y = torch.empty((T, 2 * Ho, 2 * Wo, sp.cout_pad // 4), dtype=torch.float32, device=x.device)
+            yshape = (T, 2 * Ho, 2 * Wo, sp.cout_pad // 4)
         else:
-            y = torch.empty((T, Ho, Wo, sp.cout_pad), dtype=torch.float32, device=x.device)
+            yshape = (T, Ho, Wo, sp.cout_pad)
         if out is not None:
-            if tuple(out.shape) != tuple(y.shape) or not out.is_contiguous() or out.dtype != y.dtype:
-                raise ValueError("%s: out has shape %s, expected contiguous %s" % (sp.key, tuple(out.shape), tuple(y.shape)))
+            if tuple(out.shape) != yshape or not out.is_contiguous() or out.dtype != torch.float32:
+                raise ValueError("%s: out has shape %s, expected contiguous %s" % (sp.key, tuple(out.shape), yshape))
             y = out
+        elif alloc:
+            y = torch.empty(yshape, dtype=torch.float32, device=x.device)
+        else:
+            y = None
         wp, bp = self.packed.tensors[sp.key]
         a.x = x.data_ptr()
         if sp.tsm:
@@ -191,17 +215,13 @@ class HipExecutor:
         elif sp.epilogue == EPI_RESID:
             raise ValueError("%s: the residual layer needs its base tensor" % sp.key)
         a.resid_ch = min(3, sp.cout) if sp.epilogue == EPI_RESID else 0
-        a.y = y.data_ptr()
-        a.y_frame_stride = y[0].numel()
+        if y is not None:
+            a.y = y.data_ptr()
+        a.y_frame_stride = 1
+        for d in yshape[1:]:
+            a.y_frame_stride *= d
         a.frames, a.H, a.W = T, H, W
         a.Cin, a.Cout = sp.cin_pad, sp.cout_pad
         a.stride = sp.stride
         a.act, a.epilogue, a.dtype = _lib.ACT[sp.act], sp.epilogue, self.dtype
-        if self.record_variants:
-            buf = ctypes.create_string_buffer(96)
-            _lib.check(self.lib.bsvd_conv3x3_variant(ctypes.byref(a), buf, 96), "bsvd_conv3x3_variant(%s)" % sp.key)
-            self.last_variant = buf.value.decode()
-        rc = self.lib.bsvd_conv3x3(ctypes.byref(a), _stream_ptr())
-        _lib.check(rc, "bsvd_conv3x3(%s)" % sp.key)
-        self.launches += 1
-        return y
+        return a, y

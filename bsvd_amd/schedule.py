@@ -94,8 +94,8 @@ def bsvd_clip(ex, net, x, halo_fn=None, x_planar=False, y_planar=None):
 class _TsmStage:
     """The two frame buffers around one temporal-fusion conv (BiBufferConv, bsvd_arch.py:53-114).
 
-    feed(frame t+1) returns the layer output for frame t.  ``mid`` = pending frame, ``past`` = the frame
-    before it (its channels [fold:2fold] are what ShiftConv reads; None = zeros at stream start).
+    feed(frame t+1) returns the layer output for frame t.  ``mid`` = pending frame (or chunk of frames), ``past`` = the
+    frame (chunk) before it (its channels [fold:2fold] are what ShiftConv reads; None = zeros at stream start).
     Like the reference, ``past`` survives a flush and is only cleared by reset()."""
 
     def __init__(self, spec):
@@ -117,7 +117,10 @@ class _TsmStage:
             return None
         cur, sp = self.mid, self.spec
         cpad = cur.shape[-1]
-        hp = None if self.past is None else Halo(self.past, cpad, sp.fold)
+        # a step may carry a chunk of several consecutive frames ([n,H,W,C], stream_plan's chunked streaming_forward):
+        # inside the chunk the kernel reads frames t-1 / t+1 itself; the halos are the previous chunk's LAST frame and
+        # the next chunk's FIRST frame
+        hp = None if self.past is None else Halo(self.past if self.past.shape[0] == 1 else self.past[-1:], cpad, sp.fold)
         hn = None if nxt is None else Halo(nxt, cpad, 0)
         y = ex.conv(sp, cur, halo_prev=hp, halo_next=hn)
         self.past, self.mid = cur, nxt

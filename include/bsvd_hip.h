@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BSVD_ABI_VERSION 5
+#define BSVD_ABI_VERSION 6
 
 /* dtype.  BSVD_F32: exact fp32 (v_mfma_f32_32x32x2_f32).  BSVD_F16X3 ("split16"): every fp32 value v is carried as
  * an fp16 pair hi = fp16(v), lo = fp16(v - hi); a 16-channel chunk of a pixel is stored as [hi x16 | lo x16] in the
@@ -178,6 +178,30 @@ int bsvd_halo_unpack(const void *src, void *frame, int32_t HW, int32_t C, int32_
  * library keeps working if a later version wants a workspace.  Validates `args` like bsvd_conv3x3: < 0 = bad argument.
  */
 int64_t bsvd_workspace_bytes(const BsvdConvArgs *args);
+
+/*
+ * Steady-state streaming step as ONE submission (SURVEY.md §7.1 "hipGraph-capture one steady-state step"; replaces the
+ * per-layer Python/torch dispatch under BSVD.feedin_one_element, bsvd_arch.py:485-488).
+ *
+ * bsvd_conv3x3_batch: validates and enqueues args[0..n-1] in order on `stream` (same semantics as n calls of
+ * bsvd_conv3x3); stops at the first failing layer and returns its code (bsvd_last_error() names the index).
+ *
+ * Graph capture: the host brackets a batch with bsvd_graph_begin / bsvd_graph_end on a NON-default capture stream (nothing
+ * executes while capturing), gets an executable graph handle and replays it with bsvd_graph_launch on any stream, once
+ * per frame.  All device pointers are baked into the graph, so the host keeps every buffer of a step in fixed rings
+ * (bsvd_amd/stream_plan.py).  bsvd_graph_fork / bsvd_graph_join make a second stream part of the capture so that two
+ * independent layer chains (the two DenBlocks of consecutive pipeline steps) become parallel branches of one graph.
+ * A graph handle owns no device memory; bsvd_graph_destroy releases it.  Capture mode is "relaxed": other threads of
+ * the process are not restricted while a capture is open.
+ */
+int bsvd_conv3x3_batch(const BsvdConvArgs *args, int32_t n, void *stream);
+int bsvd_graph_begin(void *capture_stream);
+int bsvd_graph_fork(void *capture_stream, void *side_stream);
+int bsvd_graph_join(void *capture_stream, void *side_stream);
+int bsvd_graph_end(void *capture_stream, void **graph_exec, int32_t *num_nodes);
+int bsvd_graph_abort(void *capture_stream);   /* ends a capture after a failed launch and discards it */
+int bsvd_graph_launch(void *graph_exec, void *stream);
+int bsvd_graph_destroy(void *graph_exec);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Stream schedule vs clip schedule on one GPU: the allocating layer-by-layer path, rings with batched launches, rings +
+HIP graphs (feedin_one_element protocol) and the lagged two-branch graph of streaming_forward.  Checks bitwise equality
+with the clip schedule and prints frames/s.    python tools/stream_modes.py [--size 540x960] [--frames 10,85] [--json out]"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bsvd_amd
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", default="540x960")
+ap.add_argument("--frames", default="10,85")
+ap.add_argument("--precision", default="f16x3")
+ap.add_argument("--reps", type=int, default=4)
+ap.add_argument("--json", default=None)
+a = ap.parse_args()
+H, W = map(int, a.size.split("x"))
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+
+
+def model(**kw):
+    torch.manual_seed(1234)
+    return bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, norm="none", act="relu6", interm_ch=64, pretrain_ckpt=None,
+                         precision=a.precision, **kw).to(dev).eval()
+
+
+def per_frame(m, x):
+    outs = [m.feedin_one_element(x[i:i + 1]) for i in range(x.shape[0])]
+    while len(outs) < x.shape[0] + m.shift_num:
+        outs.append(m.feedin_one_element(None))
+    m.feedin_one_element(None)
+    m.reset()
+    return torch.cat(outs[m.shift_num:])
+
+
+res = {"size": a.size, "precision": a.precision, "rows": []}
+for F in map(int, a.frames.split(",")):
+    x = torch.rand(F, 4, H, W, device=dev)
+    ref = None
+    variants = [("clip", dict(engine_mode="clip"), lambda m: m.clip_forward(x)),
+                ("stream alloc (r01 path, per-frame API)", dict(stream_rings=False, stream_overlap=False), lambda m: per_frame(m, x)),
+                ("stream rings, batched launches (per-frame API)", dict(stream_graphs=False, stream_overlap=False), lambda m: per_frame(m, x)),
+                ("stream rings + graphs (per-frame API)", dict(stream_overlap=False), lambda m: per_frame(m, x)),
+                ("streaming_forward chunk 1: lagged two-branch graph", dict(stream_chunk=1), lambda m: m.streaming_forward(x)),
+                ("streaming_forward chunk 1: single chain graph", dict(stream_chunk=1, stream_overlap=False), lambda m: m.streaming_forward(x)),
+                ("streaming_forward chunk 2: lagged two-branch graph", dict(stream_chunk=2), lambda m: m.streaming_forward(x)),
+                ("streaming_forward chunk 4: lagged two-branch graph", dict(stream_chunk=4), lambda m: m.streaming_forward(x)),
+                ("streaming_forward chunk 8: lagged two-branch graph", dict(stream_chunk=8), lambda m: m.streaming_forward(x)),
+                ("streaming_forward chunk 8: single chain graph", dict(stream_chunk=8, stream_overlap=False), lambda m: m.streaming_forward(x)),
+                ("streaming_forward chunk auto", dict(), lambda m: m.streaming_forward(x))]
+    if os.environ.get("ONLY"):
+        variants = [v for v in variants if any(k in v[0] for k in os.environ["ONLY"].split(","))]
+    for name, kw, fn in variants:
+        m = model(**kw)
+        with torch.no_grad():
+            y = fn(m)
+            y = fn(m)
+            y = fn(m)            # third pass: every plan is a graph replay by now
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(a.reps):
+                t0 = time.perf_counter()
+                y = fn(m)
+                torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t0)
+        if ref is None:
+            ref = y
+        same = bool(torch.equal(y, ref))
+        engs = list(m._stream_engs.values())
+        stats = {}
+        if engs:
+            e = engs[-1]
+            stats = dict(e.stats, chunk=e.chunk, ring_GB=round(sum(g.ring_bytes for g in engs) / 1e9, 2),
+                         graphs=sum(1 for g in e.graphs.values() if g[0]))
+        row = {"frames": F, "schedule": name, "fps": F / best, "ms_per_frame": best / F * 1e3, "bitwise_equal_to_clip": same, **stats}
+        res["rows"].append(row)
+        print(json.dumps(row), flush=True)
+        m.release_stream_buffers()
+        del m
+        torch.cuda.empty_cache()
+if a.json:
+    json.dump(res, open(a.json, "w"), indent=1)
