@@ -11,6 +11,13 @@ its neighbours over RCCL (bsvd_amd/dist.py) -> weak scaling; N=8 is BASELINE con
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Other BASELINE configurations (same JSON schema; the default above is what the driver runs):
+    --workload c2   bsvd_c64 sigma=30, DAVIS-2017-test-dev-480p geometry: one 85-frame 480x856 clip
+    --workload c3   blind bsvd_c64 (3-channel input, interm_ch 30, ReLU; WNet semantics), Set8 geometry: 85 x 540x960
+    --workload c5   bsvd_c64 1080p (1920x1080) streaming: 64 frames through feedin_one_element (--mode perframe)
+    --mode clip | stream (streaming_forward: rings + HIP graphs, chunked) | perframe (feedin_one_element, one graph per frame)
+    --scaling strong --total-frames 80   one fixed clip split over the ranks (N=1 and N=8 run the same C4 clip)
+
 Prints ONE JSON line on rank 0.  ``value`` = total frames / max-over-ranks wall time of the K timed steps.
 ``roofline``: per-launch HIP-event timing (on the stream the kernels run on) of the dominant kernel
 against the fp32-MFMA peak.  ``cpu_baseline``: the oracle's streaming restatement (same oneDNN conv calls
@@ -36,21 +43,38 @@ DEFAULT_PRECISION = "f16x3"
 H, W = 540, 960
 SIGMA = 30.0 / 255.0
 
+# BASELINE.json configs: geometry, frames per GPU per step, default schedule, network variant
+WORKLOADS = {
+    "c1": dict(h=540, w=960, frames=10, mode="clip", blind=False,
+               name="C1/C4 bsvd_c64 sigma=30, synthetic clip [1,%d,4,540,960]"),
+    "c2": dict(h=480, w=856, frames=85, mode="clip", blind=False,
+               name="C2 bsvd_c64 sigma=30, DAVIS-2017-test-dev-480p geometry (854x480 padded to 856x480), one %d-frame clip"),
+    "c3": dict(h=540, w=960, frames=85, mode="clip", blind=True,
+               name="C3 blind bsvd_c64 (3-channel input, interm_ch 30, ReLU, WNet semantics), Set8 geometry, one %d-frame 540x960 clip"),
+    "c5": dict(h=1080, w=1920, frames=64, mode="perframe", blind=False,
+               name="C5 bsvd_c64 sigma=30 1080p (1920x1080) streaming, %d frames"),
+}
 
-def synth_clip(frames, seed, device):
+
+def synth_clip(frames, seed, device, h=None, w=None):
     """S2 of SURVEY §8d: clean uniform clip + AWGN sigma=30/255, 4th channel = constant noise map."""
+    h, w = h or H, w or W
     g = torch.Generator(device="cpu").manual_seed(seed)
-    gt = torch.rand((1, frames, 3, H, W), generator=g)
+    gt = torch.rand((1, frames, 3, h, w), generator=g)
     lq = gt + torch.randn(gt.shape, generator=g) * SIGMA
-    nm = torch.full((1, frames, 1, H, W), SIGMA)
+    nm = torch.full((1, frames, 1, h, w), SIGMA)
     return lq.to(device), nm.to(device)
 
 
-def build_model(device, precision="fp32"):
+def build_model(device, precision="fp32", blind=False):
     import bsvd_amd
     torch.manual_seed(1234)      # random-init weights of the bsvd_c64 architecture (no checkpoint in the tree)
-    m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, shift_input=False, in_ch=4, out_ch=3, norm="none",
-                      act="relu6", interm_ch=64, blind=False, pretrain_ckpt=None, precision=precision)
+    if blind:                    # options/test/0407...blind_c64.yml:97-121: interm_ch default 30, act default relu
+        m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, shift_input=False, in_ch=4, out_ch=3, norm="none",
+                          act="relu", interm_ch=30, blind=True, pretrain_ckpt=None, precision=precision)
+    else:
+        m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, shift_input=False, in_ch=4, out_ch=3, norm="none",
+                          act="relu6", interm_ch=64, blind=False, pretrain_ckpt=None, precision=precision)
     return m.to(device).eval()
 
 
@@ -136,23 +160,25 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(model):
-    """Reference CPU path stand-in: oracle.stream_forward (per-frame pipeline, F.conv2d fp32 + torch.cat) on
-    the host cores.  Bounded sample, adaptively sized to ~10-30 s of CPU work."""
+def cpu_baseline(model, h, w, blind, frames=10):
+    """Reference CPU path stand-in: oracle.stream_forward (per-frame pipeline, F.conv2d fp32 + torch.cat,
+    the same oneDNN calls as the reference's CPU forward; timed beside the real reference in the build container:
+    profiles/cpu_ref_vs_port.json) on the host cores this process may use, on one [1,F,C,h,w] sigma=30 clip:
+    one warm-up forward + best of 2."""
     from oracle import bsvd_oracle as O
     P = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     cores = usable_cores()
     torch.set_num_threads(cores)
+    lq, nm = synth_clip(frames, 8, "cpu", h, w)
+    if blind:
+        nm = None
+    times = []
     with torch.no_grad():
-        lq, nm = synth_clip(1, 7, "cpu")
-        t0 = time.perf_counter()
-        O.stream_forward(lq, P, noise_map=nm)
-        t1 = time.perf_counter() - t0                     # includes one-off oneDNN primitive creation
-        frames = max(2, min(10, int(15.0 / max(t1, 1e-3))))
-        lq, nm = synth_clip(frames, 8, "cpu")
-        t0 = time.perf_counter()
-        O.stream_forward(lq, P, noise_map=nm)
-        dt = time.perf_counter() - t0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.stream_forward(lq, P, noise_map=nm)
+            times.append(time.perf_counter() - t0)
+    dt = min(times[1:])
     cpu = "?"
     try:
         for line in open("/proc/cpuinfo"):
@@ -162,8 +188,9 @@ def cpu_baseline(model):
     except OSError:
         pass
     return {"value": frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle.stream_forward (per-frame pipeline, torch conv2d fp32) on one [1,%d,4,540,960] sigma=30 "
-                      "clip, single run after a 1-frame warm-up; host CPU: %s" % (frames, cpu)}
+            "runs_s": times,
+            "sample": "oracle.stream_forward (per-frame pipeline, torch conv2d fp32) on one [1,%d,%d,%d,%d] sigma=30 clip, "
+                      "1 warm-up + best of 2; host CPU: %s" % (frames, 3 if blind else 4, h, w, cpu)}
 
 
 def init_groups(dist, device, rank, world):
@@ -195,17 +222,28 @@ def init_groups(dist, device, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 30 for c1, fewer for the long workloads)")
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--prewarm-s", type=float, default=0.5,
                     help="untimed seconds of the same step before the W warmup steps: the idle GPU sits at ~0.5 GHz and "
                          "needs a few hundred ms of load to reach its sustained clock (reported as prewarm_s)")
-    ap.add_argument("--frames", type=int, default=10, help="frames per GPU per step")
-    ap.add_argument("--mode", default="clip", choices=["clip", "stream"])
+    ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS), help="BASELINE.json configuration (c4 = c1 with --gpus 8)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default: the workload's)")
+    ap.add_argument("--mode", default=None, choices=["clip", "stream", "perframe"],
+                    help="clip: layer-major over the clip; stream: streaming_forward (rings + HIP graphs, chunked); perframe: "
+                         "feedin_one_element, one graph replay per frame (default: the workload's)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --frames per GPU (the job grows with N); strong: one clip of --total-frames split over the ranks")
+    ap.add_argument("--total-frames", type=int, default=80, help="--scaling strong: frames of the whole clip (C4: 80)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["fp32", "f16x3"],
                     help="fp32: exact fp32 MFMA; f16x3: split-fp16 3-pass MFMA, fp32 accumulate (fp32-class accuracy)")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    h, w = wl["h"], wl["w"]
+    mode = args.mode or wl["mode"]
+    steps = args.steps if args.steps is not None else (30 if args.workload == "c1" else 5)
+    warmup = args.warmup if args.warmup is not None else (5 if args.workload == "c1" else 2)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -218,6 +256,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1 and mode != "clip":
+        # the stream schedules keep per-stream state on one GPU (causality: a live stream does not shard in time);
+        # running them under torch.distributed.run would time N unrelated streams under a "sharded clip" label
+        raise SystemExit("--mode %s is single-GPU (replicas only); the frame-window sharded job is --mode clip" % mode)
+    if args.scaling == "strong":
+        if args.total_frames % world:
+            raise SystemExit("--total-frames %d is not divisible by %d ranks" % (args.total_frames, world))
+        frames = args.total_frames // world
+    else:
+        frames = args.frames if args.frames is not None else wl["frames"]
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     if os.environ.get("BSVD_BENCH_ONE_DEVICE"):     # test knob: all ranks on cuda:0 (exercises the N>1 code on a 1-GPU box)
         local_rank = 0
@@ -233,30 +281,43 @@ def main():
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         halo_group, halo_transport = init_groups(dist, device, rank, world)
 
-    lq, nm = synth_clip(args.frames, 100 + rank, device)       # this rank's window of the 10*N-frame clip
-    x = torch.cat([lq, nm], dim=2)[0].contiguous()             # [F,4,H,W] resident in HBM before timing
+    lq, nm = synth_clip(frames, 100 + rank, device, h, w)      # this rank's window of the clip
+    x = (lq if wl["blind"] else torch.cat([lq, nm], dim=2))[0].contiguous()   # [F,C,H,W] resident in HBM before timing
+    del lq, nm
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_run(precision, steps, warmup, prewarm_s=0.0):
+    def make_step(model, halo_fn):
+        if mode == "stream":
+            return lambda: model.streaming_forward(x)
+        if mode == "perframe":
+            S = model.shift_num
+
+            def per_frame():       # the reference's streaming_forward loop over its own per-frame API (bsvd_arch.py:517-544)
+                outs = []
+                for k in range(frames + S):
+                    y = model.feedin_one_element(x[k:k + 1] if k < frames else None)
+                    if y is not None:
+                        outs.append(y)
+                model.feedin_one_element(None)
+                model.reset()
+                return torch.cat(outs, dim=0)
+            return per_frame
+        return lambda: model.clip_forward(x, halo_fn)
+
+    def timed_run(precision, steps, warmup, prewarm_s=0.0, instrument=True):
         """W untimed + K timed steps of the hot path at `precision`; returns (model, max-over-ranks seconds, per-kernel
         launch timings, last output)."""
-        model = build_model(device, precision)
-        model.engine_mode = args.mode
+        model = build_model(device, precision, wl["blind"])
         ex = model._executor(device)
         halo_fn = None
         if world > 1:
             from bsvd_amd.dist import HaloExchanger
             halo_fn = HaloExchanger(ex, rank, world, group=halo_group)
-
-        def step():
-            if args.mode == "stream":
-                return model.streaming_forward(x)
-            return model.clip_forward(x, halo_fn)
-
+        step = make_step(model, halo_fn)
         with torch.no_grad():
             if prewarm_s > 0:                                        # clock ramp from idle, untimed
                 t_pre = time.perf_counter()
@@ -268,25 +329,53 @@ def main():
                 for _ in range(min(200, int(prewarm_s / max(float(one.item()), 1e-3)))):
                     step()
                 torch.cuda.synchronize()
-            timer = LaunchTimer(ex)
+            timer = LaunchTimer(ex) if (instrument and mode == "clip") else None
             for _ in range(warmup):
-                timer.reset()
+                if timer:
+                    timer.reset()
                 y = step()
-            if warmup:
+            if warmup and timer:
                 timer.reserve(steps)
             barrier()
-            timer.reset()
+            if timer:
+                timer.reset()
             t0 = time.perf_counter()
             for _ in range(steps):
                 y = step()
             barrier()
             dt = time.perf_counter() - t0
-            timer.detach()
-        assert tuple(y.shape) == (args.frames, 3, H, W) and bool(torch.isfinite(y).all())
+            agg = None
+            if timer:
+                timer.detach()
+                agg = timer.summary()
+            elif instrument:
+                # stream schedules replay HIP graphs (no per-launch host call to bracket): the per-kernel table comes from one
+                # extra, untimed pass of the same step with the engine issuing the same plans layer by layer
+                model.bench_stream_stats = None
+                if model._stream_engs:
+                    e = list(model._stream_engs.values())[-1]
+                    model.bench_stream_stats = dict(e.stats, chunk=e.chunk, ring_GB=round(e.ring_bytes / 1e9, 2),
+                                                    graphs=sum(1 for g in e.graphs.values() if g[0]), plans=len(e.plans))
+                for e in model._stream_engs.values():
+                    e.layerwise = True
+                timer = LaunchTimer(ex)
+                step()
+                timer.reset()
+                step()
+                torch.cuda.synchronize()
+                timer.detach()
+                agg = timer.summary()
+                for v in agg.values():         # scale to `steps` so that roofline_of's per-step figures stay per step
+                    v["ms"] *= steps
+                    v["flop"] *= steps
+                    v["launches"] *= steps
+                for e in model._stream_engs.values():
+                    e.layerwise = False
+        assert tuple(y.shape) == (frames, 3, h, w) and bool(torch.isfinite(y).all())
         t_max = torch.tensor([dt], dtype=torch.float64)
         if dist is not None:
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        return model, float(t_max.item()), timer.summary(), y
+        return model, float(t_max.item()), agg, y
 
     def roofline_of(agg, precision, steps):
         peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_F16_MFMA_TFLOPS
@@ -295,13 +384,17 @@ def main():
         traffic, traffic_src = None, None
         try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/make_traffic.py)
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/traffic.json (%s; %s)" % (tj["source"], tj["formula"])
+            if args.workload == "c1" and mode == "clip" and frames == 10:      # the table was collected on this workload
+                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/traffic.json (%s; %s)" % (tj["source"], tj["formula"])
         except (OSError, KeyError, ValueError):
             pass
         return {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, separate passes)",
                 "traffic_source": traffic_src,
+                "timing": "HIP events around every launch inside the timed region" if mode == "clip" else
+                          "HIP events around every launch in one extra untimed pass of the same step plans issued layer by layer "
+                          "(the timed region replays them as HIP graphs)",
                 "note": ("algorithmic FLOP over the fp32-MFMA peak (v_mfma_f32_32x32x2_f32)" if precision == "fp32" else
                          "algorithmic FLOP over the dense fp16-MFMA peak; the 3-pass split issues 3 MFMA FLOP per "
                          "algorithmic FLOP, so MFMA-pipe utilisation = 3 x frac (mfma_pipe_frac).  The chip runs this at its "
@@ -315,47 +408,61 @@ def main():
                 "conv_ms_per_step": sum(v["ms"] for v in agg.values()) / steps}
 
     # ---- the timed job (headline) ...
-    model, elapsed, agg, y = timed_run(args.precision, args.steps, args.warmup, args.prewarm_s)
+    model, elapsed, agg, y = timed_run(args.precision, steps, warmup, args.prewarm_s)
+    stream_stats = getattr(model, "bench_stream_stats", None)
+    model.release_stream_buffers()
     # ---- ... and, outside it, the other arithmetic mode on the same clip for reference + a live parity figure
     other = "fp32" if args.precision == "f16x3" else "f16x3"
-    _, elapsed_o, agg_o, y_o = timed_run(other, max(1, min(args.steps, 3)), 1)
-    steps_o = max(1, min(args.steps, 3))
+    steps_o = max(1, min(steps, 3))
+    model_o, elapsed_o, agg_o, y_o = timed_run(other, steps_o, 1)
+    model_o.release_stream_buffers()
     parity = float((y.float() - y_o.float()).abs().max())
 
     if rank == 0:
-        total_frames = args.frames * world * args.steps
+        total_frames = frames * world * steps
         fps = total_frames / elapsed
-        flop_per_frame = 2.0 * model.net.macs_per_frame(H, W)
+        flop_per_frame = 2.0 * model.net.macs_per_frame(h, w)
+        degraded = bool(halo_transport) and not halo_transport.startswith("rccl")
+        api = {"clip": "BSVD.forward (clip schedule: layer-major, 32 launches per clip)",
+               "stream": "BSVD.streaming_forward (stream schedule on rings, HIP-graph replay, %s frames per pipeline step)"
+                         % (stream_stats["chunk"] if stream_stats else "?"),
+               "perframe": "BSVD.feedin_one_element per frame + 17 flush feeds (one HIP-graph replay per frame)"}[mode]
         out = {
-            "metric": "denoised frames/sec @540x960 sigma=30 (bsvd_c64 streaming bidirectional-buffer forward)",
-            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_s": args.prewarm_s,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": "denoised frames/sec @%dx%d sigma=30 (bsvd_c64 streaming bidirectional-buffer forward)" % (h, w),
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup, "prewarm_s": args.prewarm_s,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             # the reference's own published 28.3 frames/s for BSVD.forward on this very clip shape (one
             # unnamed CUDA GPU, fp16 weights + autocast) -- a single-GPU number, so the ratio is reported at N = 1 only
-            "vs_baseline": (fps / REFERENCE_PUBLISHED_FPS) if world == 1 else None,
+            "vs_baseline": (fps / REFERENCE_PUBLISHED_FPS) if (world == 1 and args.workload == "c1") else None,
             "vs_baseline_source": "BASELINE.md s1: 0.353594 s per [1,10,4,540,960] clip = 28.3 frames/s (reference README.md:88-106; "
                                   "other hardware, fp16 autocast)",
             "dtype": "f32" if args.precision == "fp32" else "f16x3 (split-fp16 MFMA, fp32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": "bsvd_c64 sigma=30, one synthetic clip [1,%d,4,540,960], %s schedule, "
-                                   "random-init weights; N>1: frame-window sharded with per-layer RCCL halo"
-                                   % (args.frames * world, args.mode),
-                       "frames_per_gpu": args.frames, "parallelism": "frame-window x%d" % world,
-                       "halo_transport": halo_transport,
+            "config": {"workload": (wl["name"] % (frames * world)) + ", %s, random-init weights%s"
+                                   % (api, "; frame-window sharded with per-layer RCCL halo" if world > 1 else ""),
+                       "baseline_config": args.workload if world == 1 or args.workload != "c1" else "c4" if frames * world == 80 else "c1 x%d" % world,
+                       "frames_per_gpu": frames, "parallelism": "frame-window x%d" % world,
+                       "schedule": mode, "halo_transport": halo_transport,
                        "flop_per_frame": flop_per_frame},
+            # true when the halo slices of an N>1 run did NOT travel over RCCL/xGMI (host-staged gloo fallback): such a line is a
+            # functional check, not a scaling measurement
+            "degraded": degraded,
             "path_tflops": fps * flop_per_frame / 1e12,
             "path_frac_of_mfma_peak": fps * flop_per_frame / 1e12 /
                                       ((PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_F16_MFMA_TFLOPS) * world),
-            "roofline": roofline_of(agg, args.precision, args.steps),
+            "roofline": roofline_of(agg, args.precision, steps),
             "parity": {"max_abs_f16x3_vs_exact_fp32_on_this_clip": parity, "budget": 1e-3,
                        "note": "north_star: <= 1e-3 max-abs vs the fp32 forward; tests/test_gpu_f16x3.py pins 3-6e-5 vs "
                                "the reference goldens"},
-            "other_mode": {"dtype": "f32" if other == "fp32" else "f16x3", "value": args.frames * world * steps_o / elapsed_o,
+            "other_mode": {"dtype": "f32" if other == "fp32" else "f16x3", "value": frames * world * steps_o / elapsed_o,
                            "unit": "frames/s", "steps": steps_o, "ms_per_step": elapsed_o / steps_o * 1e3,
                            "roofline": roofline_of(agg_o, other, steps_o)},
         }
+        if stream_stats:
+            out["stream_engine"] = stream_stats
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model)
+            # bounded sample of the same workload: 10 frames of its geometry (4 at 1080p), the CPU path's cost is linear in frames
+            out["cpu_baseline"] = cpu_baseline(model, h, w, wl["blind"], frames=4 if h * w > 540 * 960 else 10)
         else:
             out["cpu_baseline"] = None
         sys.stdout.flush()

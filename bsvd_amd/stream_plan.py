@@ -157,6 +157,7 @@ class StreamEngine:
         self.graphs = OrderedDict()
         self.max_graphs = max_graphs
         self.stats = {"graph_replays": 0, "graph_captures": 0, "batch_launches": 0, "steps": 0}
+        self.layerwise = False      # measurement aid: issue every plan layer by layer through ex.conv (per-launch HIP events)
         self._cap = self._side = None
         self._lag = None            # streaming_forward: DenBlock 1's output of the previous step, not yet fed to DenBlock 2
 
@@ -231,7 +232,7 @@ class StreamEngine:
 
     def _issue(self, key, plans_main, plans_side):
         """plans_main run in order; plans_side (optional) are independent of them (a parallel graph branch)."""
-        if not self.hip:
+        if not self.hip or self.layerwise:
             for p in list(plans_side) + list(plans_main):
                 self._issue_generic(p)
             return

@@ -90,8 +90,13 @@ def import_reference_tsn():
 
 
 def import_reference_callers():
-    """validation_seq_infer.denoise_seq and DenoisingModel.padding_input/crop_output (stubbed imports)."""
+    """validation_seq_infer.denoise_seq and DenoisingModel.padding_input/crop_output (stubbed imports).  Idempotent: the
+    modules are executed once (denoising_model.py registers DenoisingModel in MODEL_REGISTRY, which asserts on a second
+    registration) and served from sys.modules afterwards."""
     import_reference()
+    if "Experimental_root.models.denoising_model" in sys.modules and "Experimental_root.models.validation_seq_infer" in sys.modules:
+        return (sys.modules["Experimental_root.models.validation_seq_infer"],
+                sys.modules["Experimental_root.models.denoising_model"])
     if "Experimental_root.models.global_queue_buffer" in sys.modules:
         gq = sys.modules["Experimental_root.models.global_queue_buffer"]
     else:
@@ -129,8 +134,11 @@ def load_seeded(module, seed):
     return st
 
 
+OUT_DIR = HERE        # main(out_dir) redirects it (tests/test_golden_recipe.py regenerates into a tmp dir)
+
+
 def save(name, **arrays):
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **arrays)
     print("wrote %-34s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
 
@@ -421,11 +429,11 @@ def g8_pad_crop_clamp():
          seen_nm=np.array(dummy.seen[1]), seen_sigma=np.float32(dummy.seen[2]))
 
 
-def g9_psnr():
-    """calculate_psnr (uint8 domain) / calculate_psnr_float of the reference
-    (BasicSR/basicsr/metrics/psnr_ssim.py:9-45, 130-168) on a seeded pair with crop_border=2.
-    cv2 is absent in the container; it is only used by _ssim, so an empty stub module is enough here."""
+def g9_psnr_modules():
+    """loads the reference's metric modules (psnr_ssim.py, metric_util.py) once; cv2 / matlab_functions as empty stubs"""
     import_reference()
+    if "basicsr.metrics.psnr_ssim" in sys.modules:
+        return sys.modules["basicsr.metrics.psnr_ssim"]
     for name in ("cv2", "basicsr.utils.matlab_functions"):
         if name not in sys.modules:
             m = types.ModuleType(name)
@@ -436,7 +444,14 @@ def g9_psnr():
         mm.__path__ = []
         sys.modules["basicsr.metrics"] = mm
     _load("basicsr.metrics.metric_util", os.path.join(REF, "BasicSR/basicsr/metrics/metric_util.py"))
-    ps = _load("basicsr.metrics.psnr_ssim", os.path.join(REF, "BasicSR/basicsr/metrics/psnr_ssim.py"))
+    return _load("basicsr.metrics.psnr_ssim", os.path.join(REF, "BasicSR/basicsr/metrics/psnr_ssim.py"))
+
+
+def g9_psnr():
+    """calculate_psnr (uint8 domain) / calculate_psnr_float of the reference
+    (BasicSR/basicsr/metrics/psnr_ssim.py:9-45, 130-168) on a seeded pair with crop_border=2.
+    cv2 is absent in the container; it is only used by _ssim, so an empty stub module is enough here."""
+    ps = g9_psnr_modules()
     rs = np.random.RandomState(901)
     gt = rs.uniform(0, 1, (3, 16, 20)).astype(np.float32)
     out = np.clip(gt + rs.standard_normal(gt.shape).astype(np.float32) * 0.05, 0, 1).astype(np.float32)
@@ -446,6 +461,56 @@ def g9_psnr():
     p8_nocrop = ps.calculate_psnr(to_u8(out), to_u8(gt), crop_border=0)
     save("g9_psnr", gt=gt, out=out, psnr_u8=np.float64(p8), psnr_float=np.float64(pf), psnr_u8_nocrop=np.float64(p8_nocrop))
     print("   psnr uint8 %.5f  float %.5f" % (p8, pf))
+
+
+def _cv2_standins():
+    """cv2 is absent in the container.  The reference's SSIM (psnr_ssim.py:49-81) uses two OpenCV primitives; they are
+    stood in for by their documented definitions so that the reference's OWN _ssim / calculate_ssim code runs:
+      getGaussianKernel(n, sigma): G_i = a * exp(-(i - (n-1)/2)^2 / (2 sigma^2)), sum G = 1, float64 column vector;
+      filter2D(src, -1, kernel): correlation with the kernel anchored at its centre, same size, BORDER_REFLECT_101
+      (= scipy 'mirror'); the reference only keeps [5:-5, 5:-5], which no border rule touches."""
+    from scipy import ndimage
+    cv2 = sys.modules.get("cv2") or types.ModuleType("cv2")
+
+    def getGaussianKernel(ksize, sigma):
+        x = np.arange(ksize, dtype=np.float64) - (ksize - 1) / 2.0
+        g = np.exp(-(x * x) / (2.0 * sigma * sigma))
+        return (g / g.sum()).reshape(ksize, 1)
+
+    def filter2D(src, ddepth, kernel):
+        assert ddepth == -1
+        return ndimage.correlate(np.asarray(src), np.asarray(kernel), mode="mirror")
+
+    cv2.getGaussianKernel, cv2.filter2D = getGaussianKernel, filter2D
+    sys.modules["cv2"] = cv2
+    return cv2
+
+
+def g12_ssim():
+    """calculate_ssim of the reference (BasicSR/basicsr/metrics/psnr_ssim.py:49-128: 11x11 Gaussian window sigma 1.5, valid
+    region, per-channel mean) executed on seeded uint8 image pairs, crop_border 2 and 0, HWC and CHW input order."""
+    g9_psnr_modules()
+    _cv2_standins()
+    ps = sys.modules["basicsr.metrics.psnr_ssim"]
+    rs = np.random.RandomState(1201)
+    out = {}
+    for tag, shape in (("a", (24, 32, 3)), ("b", (16, 20, 3)), ("c", (40, 28, 1))):
+        gt = rs.uniform(0, 255, shape)
+        gt = np.clip(ndimage_smooth(gt), 0, 255).round().astype(np.uint8)
+        noisy = np.clip(gt.astype(np.float64) + rs.standard_normal(shape) * 12.0, 0, 255).round().astype(np.uint8)
+        out["gt_" + tag], out["img_" + tag] = gt, noisy
+        out["ssim_crop2_" + tag] = np.float64(ps.calculate_ssim(noisy, gt, crop_border=2))
+        out["ssim_crop0_" + tag] = np.float64(ps.calculate_ssim(noisy, gt, crop_border=0))
+        out["ssim_chw_" + tag] = np.float64(ps.calculate_ssim(noisy.transpose(2, 0, 1), gt.transpose(2, 0, 1), crop_border=2,
+                                                              input_order="CHW"))
+        print("   ssim %s crop2 %.6f crop0 %.6f" % (tag, out["ssim_crop2_" + tag], out["ssim_crop0_" + tag]))
+    save("g12_ssim", **out)
+
+
+def ndimage_smooth(a):
+    """low-pass so that the pair has image-like structure (SSIM of white noise is uninformative)"""
+    from scipy import ndimage
+    return ndimage.uniform_filter(a, size=(5, 5, 1), mode="nearest") * 1.6 - 60.0
 
 
 def g10_mimo_segments():
@@ -496,7 +561,9 @@ def g11_seeded_init():
     save("g11_seeded_init", **out)
 
 
-def main():
+def main(out_dir=None):
+    global OUT_DIR
+    OUT_DIR = out_dir or HERE
     torch.manual_seed(0)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     ref = import_reference()
@@ -514,6 +581,7 @@ def main():
     g9_psnr()
     g10_mimo_segments()
     g11_seeded_init()
+    g12_ssim()
 
 
 if __name__ == "__main__":

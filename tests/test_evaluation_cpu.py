@@ -27,6 +27,17 @@ def test_tensor2img_clamps_rounds_and_swaps_channels():
     assert img[0, 0].tolist() == [255, 0, 0] and img[0, 1].tolist() == [254, 0, 2]
 
 
+def test_ssim_against_the_reference_golden():
+    """g12: the reference's own _ssim / calculate_ssim (psnr_ssim.py:49-128) on seeded uint8 pairs."""
+    g = load_golden("g12_ssim")
+    for tag in "abc":
+        gt, img = g["gt_" + tag], g["img_" + tag]
+        assert abs(E.calculate_ssim(img, gt, crop_border=2) - float(g["ssim_crop2_" + tag])) < 1e-10
+        assert abs(E.calculate_ssim(img, gt, crop_border=0) - float(g["ssim_crop0_" + tag])) < 1e-10
+        chw = E.calculate_ssim(img.transpose(2, 0, 1), gt.transpose(2, 0, 1), crop_border=2, input_order="CHW")
+        assert abs(chw - float(g["ssim_chw_" + tag])) < 1e-10
+
+
 def test_ssim_against_direct_window_sum():
     rs = np.random.RandomState(3)
     a = rs.randint(0, 256, (20, 24, 3)).astype(np.uint8)

@@ -3,7 +3,8 @@
 the oracle's restatement (oracle.bsvd_oracle.stream_forward -- what bench.py's cpu_baseline times on the GPU box) on the
 same clip, weights and thread count, and checks that both produce the same tensor.  SURVEY 8d: this legitimises the
 restatement as the CPU stand-in where /root/reference does not exist.
-usage: python tools/cpu_ref_vs_port.py [frames=4] [H=540] [W=960]"""
+usage: python tools/cpu_ref_vs_port.py [frames=4] [H=540] [W=960] [out.json]   (writes profiles/cpu_ref_vs_port.json by default)"""
+import json
 import os
 import sys
 import time
@@ -16,6 +17,9 @@ import torch                # noqa: E402
 import make_golden as MG    # noqa: E402
 from seeded import seeded_clip   # noqa: E402
 from oracle import bsvd_oracle as O   # noqa: E402
+
+
+RUNS = {}
 
 
 def main():
@@ -33,6 +37,8 @@ def main():
     legs = (("reference BSVD.forward (bsvd_arch.py:490-552)", lambda: net(x)[0]),
             ("oracle.stream_forward (restatement)", lambda: O.stream_forward(x, P)[0]))
     res = {name: [1e30, None] for name, _ in legs}
+    for name, _ in legs:
+        RUNS[name] = []
     with torch.no_grad():
         for it in range(3):                       # interleaved, best of 3 (the container's cores are shared)
             for name, fn in legs:
@@ -40,12 +46,27 @@ def main():
                 out = fn()
                 dt = time.perf_counter() - t0
                 res[name] = [min(res[name][0], dt), out]
+                RUNS[name].append(dt)
                 print("  run %d %-46s %.2f s" % (it, name, dt), flush=True)
     for name, (best, _) in res.items():
         print("%-48s %.2f s for %d frames = %.3f frames/s (%d threads, %dx%d)" % (name, best, F, F / best, threads, H, W))
     (ta, a), (tb, b) = res.values()
-    print("max-abs difference between the two outputs: %.3e   time ratio port/reference: %.3f"
-          % (float((a - b).abs().max()), tb / ta))
+    diff = float((a - b).abs().max())
+    print("max-abs difference between the two outputs: %.3e   time ratio port/reference: %.3f" % (diff, tb / ta))
+    cpu = "?"
+    for line in open("/proc/cpuinfo"):
+        if line.startswith("model name"):
+            cpu = line.split(":", 1)[1].strip()
+            break
+    out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "cpu_ref_vs_port.json")
+    json.dump({"what": "the REAL reference BSVD.forward (/root/reference, imported read-only) timed beside the oracle restatement "
+                       "that bench.py's cpu_baseline uses where the reference cannot travel; same clip, weights, threads; "
+                       "interleaved, best of 3",
+               "clip": [1, F, 4, H, W], "threads": threads, "cpu": cpu, "torch": torch.__version__,
+               "reference_s": ta, "port_s": tb, "reference_fps": F / ta, "port_fps": F / tb, "port_over_reference_time": tb / ta,
+               "max_abs_difference": diff, "bit_identical": diff == 0.0,
+               "all_runs_s": {k: v for k, v in RUNS.items()}}, open(out, "w"), indent=1)
+    print("wrote", out)
 
 
 if __name__ == "__main__":
