@@ -7,12 +7,14 @@ drivers work unchanged -- but everything under ``forward`` runs as hand-written 
 the C ABI (include/bsvd_hip.h).  The module tree only HOLDS the parameters (so ``state_dict()``,
 ``.to()``, ``.half()``, ``.parameters()`` behave as in the reference); it is never called layer by layer.
 """
+from collections import OrderedDict
+
 import numpy as np
 import torch
 import torch.nn as nn
 
 from . import checkpoint
-from .netspec import clip_peak_bytes, make_netspec
+from .netspec import clip_peak_bytes, make_netspec, norm_key_after
 from .registry import register_arch
 from .schedule import StreamPipeline, bsvd_clip, planar_ok
 
@@ -31,41 +33,72 @@ def _conv(cin, cout, stride=1):
     return nn.Conv2d(cin, cout, 3, stride=stride, padding=1, bias=True)
 
 
-def _mem(c):
-    return _Slots(c1=_Slots(op=_Slots(conv=_conv(c, c))), c2=_Slots(op=_Slots(conv=_conv(c, c))))
+def _mem(c, norm="none"):
+    kids = OrderedDict(c1=_Slots(op=_Slots(conv=_conv(c, c))))
+    if norm == "bn":
+        kids["b1"] = nn.BatchNorm2d(c)
+    kids["c2"] = _Slots(op=_Slots(conv=_conv(c, c)))
+    if norm == "bn":
+        kids["b2"] = nn.BatchNorm2d(c)
+    return _Slots(**kids)
 
 
-def _denblock_params(chns, in_ch, out_ch, interm_ch, blind):
+def _seq(norm, *items):
+    """nn.Sequential-style numbering of the reference's conv blocks: items = (index, module | ('bn', channels))"""
+    d = OrderedDict()
+    for idx, m in items:
+        if isinstance(m, tuple):
+            if norm == "bn":
+                d[str(idx)] = nn.BatchNorm2d(m[1])
+        else:
+            d[str(idx)] = m
+    return nn.ModuleDict(d)
+
+
+def _denblock_params(chns, in_ch, out_ch, interm_ch, blind, norm="none"):
+    """Parameter holders under the reference's names (bsvd_arch.py:116-306, 325-347); norm='bn' adds the BatchNorm2d
+    modules where get_norm_function puts them, so that a reference state_dict loads key for key."""
     c0, c1, c2 = chns
     if blind:
         in_ch = 3
     return _Slots(
-        inc=_Slots(convblock=nn.ModuleDict({"0": _conv(in_ch, interm_ch), "3": _conv(interm_ch, c0)})),
-        downc0=_Slots(convblock=nn.ModuleDict({"0": _conv(c0, c1, 2)}), memconv=_mem(c1)),
-        downc1=_Slots(convblock=nn.ModuleDict({"0": _conv(c1, c2, 2)}), memconv=_mem(c2)),
-        upc2=_Slots(memconv=_mem(c2), convblock=nn.ModuleDict({"0": _conv(c2, 4 * c1)})),
-        upc1=_Slots(memconv=_mem(c1), convblock=nn.ModuleDict({"0": _conv(c1, 4 * c0)})),
-        outc=_Slots(convblock=nn.ModuleDict({"0": _conv(c0, c0), "3": _conv(c0, out_ch)})),
+        inc=_Slots(convblock=_seq(norm, (0, _conv(in_ch, interm_ch)), (1, ("bn", interm_ch)), (3, _conv(interm_ch, c0)),
+                                  (4, ("bn", c0)))),
+        downc0=_Slots(convblock=_seq(norm, (0, _conv(c0, c1, 2)), (1, ("bn", c1))), memconv=_mem(c1, norm)),
+        downc1=_Slots(convblock=_seq(norm, (0, _conv(c1, c2, 2)), (1, ("bn", c2))), memconv=_mem(c2, norm)),
+        upc2=_Slots(memconv=_mem(c2, norm), convblock=_seq(norm, (0, _conv(c2, 4 * c1)))),
+        upc1=_Slots(memconv=_mem(c1, norm), convblock=_seq(norm, (0, _conv(c1, 4 * c0)))),
+        outc=_Slots(convblock=_seq(norm, (0, _conv(c0, c0)), (1, ("bn", c0)), (3, _conv(c0, out_ch)))),
     )
 
 
 class _HipNet(nn.Module):
     """Shared engine plumbing of the registered arch classes: NetSpec, precision, weight (re)packing, executor."""
 
-    def _init_engine(self, net, precision, clamp):
-        if precision not in ("fp32", "f16x3"):
-            raise ValueError("precision must be 'fp32' or 'f16x3'")
+    def _init_engine(self, net, precision, clamp, norm='none'):
+        if precision not in ("auto", "fp32", "f16x3"):
+            raise ValueError("precision must be 'auto', 'fp32' or 'f16x3'")
+        if norm not in ("none", "bn"):
+            raise NotImplementedError("norm=%r: 'none' (the shipped configs, options/test/bsvd_c64.yml:90) and 'bn' (the "
+                                      "constructor default; eval-mode statistics folded into the packed conv weights) are "
+                                      "implemented; InstanceNorm needs per-frame statistics and is not" % (norm,))
         self.net = net
         self.clamp = clamp
+        self.norm = norm
+        # channel counts that are not multiples of 16 ride on zero padding channels (e.g. interm_ch = 30 of the blind
+        # config); a temporal-fusion layer needs whole 16-channel chunks per temporal source: fold % 16 == 0
+        bad = [l.key for l in net.layers if l.tsm and l.fold % 16 and not (l.fold == 8 and l.cout_pad <= 64)]
+        split_ok = not bad and net.net_in_ch in (3, 4) and net.out_ch <= 4
+        self.precision_requested = precision
+        if precision == "auto":
+            # the split-fp16 mode carries fp32-class accuracy (2-6e-5 vs the reference goldens, budget 1e-3) at ~3x the
+            # rate: take it whenever the network's channel layout admits it (the c64 / c32-sized networks do)
+            precision = "f16x3" if split_ok else "fp32"
+        elif precision == "f16x3" and not split_ok:
+            raise ValueError("precision='f16x3' needs temporal-fusion layers with fold % 16 == 0 or 64 channels (fold 8), "
+                             "i.e. chns[1:] = (64|128k, 128k) like the c64 and c32 networks, and <= 4 input/output "
+                             "channels; offending layers: %s" % (bad[:3],))
         self.precision = precision
-        if precision == "f16x3":
-            # channel counts that are not multiples of 16 ride on zero padding channels (e.g. interm_ch = 30 of the blind
-            # config); a temporal-fusion layer needs whole 16-channel chunks per temporal source: fold % 16 == 0
-            bad = [l.key for l in net.layers if l.tsm and l.fold % 16 and not (l.fold == 8 and l.cout_pad <= 64)]
-            if bad or net.net_in_ch not in (3, 4) or net.out_ch > 4:
-                raise ValueError("precision='f16x3' needs temporal-fusion layers with fold % 16 == 0 or 64 channels (fold 8), "
-                                 "i.e. chns[1:] = (64|128k, 128k) like the c64 and c32 networks, and <= 4 input/output "
-                                 "channels; offending layers: %s" % (bad[:3],))
         self._packed = None
         self._packed_sig = None
         self._exec = None
@@ -83,15 +116,28 @@ class _HipNet(nn.Module):
         for m in root.modules():
             cls.weight_init(m)
 
-    def _engine_state(self):
-        """state_dict in BSVD key names (what netspec / PackedNet index by)."""
+    def _bsvd_state(self):
+        """state_dict in BSVD key names"""
         return self.state_dict()
 
+    def _engine_state(self):
+        """conv weights / biases in BSVD key names (what netspec / PackedNet index by); norm='bn': with the eval-mode
+        BatchNorm of every conv folded in."""
+        st = self._bsvd_state()
+        if self.norm == "bn":
+            st = checkpoint.fold_batchnorm(st, [l.key for l in self.net.layers], norm_key_after)
+        return st
+
     def _signature(self):
-        return tuple((p.data_ptr(), p._version, str(p.device), p.dtype) for p in self.parameters())
+        # parameters AND buffers (BatchNorm running statistics): any in-place update re-packs the weights
+        return tuple((t.data_ptr(), t._version, str(t.device), t.dtype) for t in list(self.parameters()) + list(self.buffers()))
 
     def _executor(self, device):
         from .engine import HipExecutor, PackedNet, require_hip
+        if self.norm == "bn" and self.training:
+            raise RuntimeError("norm='bn' runs with the BatchNorm layers folded into the conv weights, i.e. with eval-mode "
+                               "running statistics; call .eval() first (DenoisingModel.test and profile.py do: "
+                               "denoising_model.py:180, profile.py:80).  Training is out of scope of this engine.")
         require_hip()
         sig = (self._signature(), str(device), self.precision)
         if self._packed is None or self._packed_sig != sig:
@@ -154,25 +200,25 @@ class BSVD(_HipNet):
                     HIP graph (both default True; False = the allocating layer-by-layer path / batched launches).
       stream_chunk : frames per pipeline step of streaming_forward ('auto': up to 8 as memory allows; 1 = the reference's
                     frame-by-frame pipeline).  feedin_one_element always runs one frame per step.
-      precision   : 'fp32' (default; exact fp32 MFMA, bitwise an fmaf chain) or 'f16x3' (split-fp16 3-pass MFMA with
-                    fp32 accumulation: fp32-class accuracy -- 2-4e-5 max-abs on bsvd_c64, budget 1e-3 -- at several
-                    times the throughput).  'f16x3' needs 64-channel or 128k-channel temporal-fusion layers (fold 8 or fold % 16 == 0).
+      precision   : 'f16x3' (split-fp16 3-pass MFMA with fp32 accumulation: fp32-class accuracy -- 2-6e-5 max-abs on
+                    bsvd_c64, budget 1e-3 -- at ~3x the throughput; needs 64-channel or 128k-channel temporal-fusion layers:
+                    fold 8 or fold % 16 == 0), 'fp32' (exact fp32 MFMA, bitwise an fmaf chain) or 'auto' (default: 'f16x3'
+                    when the network admits it, else 'fp32'; ``self.precision`` holds the choice).
+      norm        : 'none' or 'bn' (the reference default; eval mode only: the BatchNorm layers hold their parameters
+                    under the reference's names and are folded into the packed conv weights).
     """
 
     def __init__(self, chns=[32, 64, 128], mid_ch=3, shift_input=False, in_ch=4, out_ch=3, norm='bn', act='relu',
                  interm_ch=30, blind=False, pretrain_ckpt='./experiments/pretrained_ckpt/bsvd-64.pth',
-                 engine_mode='auto', clamp=None, precision='fp32', stream_overlap=True, stream_rings=True,
+                 engine_mode='auto', clamp=None, precision='auto', stream_overlap=True, stream_rings=True,
                  stream_graphs=True, stream_chunk='auto'):
         super().__init__()
         if shift_input:
             raise NotImplementedError("shift_input=True (CvBlock input stage) is not used by any BSVD config; "
                                       "the reference itself is inconsistent there (SURVEY.md §8a-16)")
-        if norm != 'none':
-            raise NotImplementedError("norm=%r: the BSVD configs use norm='none' (options/test/bsvd_c64.yml:90); "
-                                      "normalisation layers are not implemented by the MI355X engine" % (norm,))
         if engine_mode not in ("auto", "clip", "stream"):
             raise ValueError("engine_mode must be 'auto', 'clip' or 'stream'")
-        self._init_engine(make_netspec(chns, mid_ch, in_ch, out_ch, act, interm_ch, blind), precision, clamp)
+        self._init_engine(make_netspec(chns, mid_ch, in_ch, out_ch, act, interm_ch, blind), precision, clamp, norm)
         self.engine_mode = engine_mode
         self.last_mode = None          # schedule the last forward() actually ran ('clip' | 'stream')
         self.stream_overlap = bool(stream_overlap)   # streaming_forward: temp1(step k) and temp2(step k-1) as parallel graph branches
@@ -183,9 +229,9 @@ class BSVD(_HipNet):
         # Same RNG consumption as the reference constructor (each DenBlock re-initialises itself, then BSVD does it
         # again, bsvd_arch.py:350,453): a seeded run draws the same weights AND leaves the generator in the same state,
         # so the evaluation noise that follows (ValFolderDataset) is the reference's realisation.
-        self.temp1 = _denblock_params(self.net.chns, in_ch, mid_ch, interm_ch, blind)
+        self.temp1 = _denblock_params(self.net.chns, in_ch, mid_ch, interm_ch, blind, norm)
         self._reset(self.temp1)
-        self.temp2 = _denblock_params(self.net.chns, mid_ch, out_ch, interm_ch, False)
+        self.temp2 = _denblock_params(self.net.chns, mid_ch, out_ch, interm_ch, False, norm)
         self._reset(self.temp2)
         self.shift_num = self.net.shift_num
         self.reset_params()
@@ -385,22 +431,29 @@ class BSVD(_HipNet):
         return self.net.shift_num
 
 
-def _tsn_denblock_params(chns, in_ch, out_ch, interm_ch, blind):
+def _tsn_denblock_params(chns, in_ch, out_ch, interm_ch, blind, norm="none"):
     """Parameter holders under the TSN/WNet key names (wnet_models.py:126-170; TemporalShift wraps c1/c2 as `.net`)."""
     c0, c1, c2 = chns
     if blind:
         in_ch = 3
 
     def cv(c):
-        return _Slots(c1=_Slots(net=_conv(c, c)), c2=_Slots(net=_conv(c, c)))
+        kids = OrderedDict(c1=_Slots(net=_conv(c, c)))
+        if norm == "bn":
+            kids["b1"] = nn.BatchNorm2d(c)
+        kids["c2"] = _Slots(net=_conv(c, c))
+        if norm == "bn":
+            kids["b2"] = nn.BatchNorm2d(c)
+        return _Slots(**kids)
 
     return _Slots(
-        inc=_Slots(convblock=nn.ModuleDict({"0": _conv(in_ch, interm_ch), "3": _conv(interm_ch, c0)})),
-        downc0=_Slots(convblock=nn.ModuleDict({"0": _conv(c0, c1, 2), "3": cv(c1)})),
-        downc1=_Slots(convblock=nn.ModuleDict({"0": _conv(c1, c2, 2), "3": cv(c2)})),
-        upc2=_Slots(convblock=nn.ModuleDict({"0": cv(c2), "1": _conv(c2, 4 * c1)})),
-        upc1=_Slots(convblock=nn.ModuleDict({"0": cv(c1), "1": _conv(c1, 4 * c0)})),
-        outc=_Slots(convblock=nn.ModuleDict({"0": _conv(c0, c0), "3": _conv(c0, out_ch)})),
+        inc=_Slots(convblock=_seq(norm, (0, _conv(in_ch, interm_ch)), (1, ("bn", interm_ch)), (3, _conv(interm_ch, c0)),
+                                  (4, ("bn", c0)))),
+        downc0=_Slots(convblock=_seq(norm, (0, _conv(c0, c1, 2)), (1, ("bn", c1)), (3, cv(c1)))),
+        downc1=_Slots(convblock=_seq(norm, (0, _conv(c1, c2, 2)), (1, ("bn", c2)), (3, cv(c2)))),
+        upc2=_Slots(convblock=_seq(norm, (0, cv(c2)), (1, _conv(c2, 4 * c1)))),
+        upc1=_Slots(convblock=_seq(norm, (0, cv(c1)), (1, _conv(c1, 4 * c0)))),
+        outc=_Slots(convblock=_seq(norm, (0, _conv(c0, c0)), (1, ("bn", c0)), (3, _conv(c0, out_ch)))),
     )
 
 
@@ -418,7 +471,11 @@ class _QueueHalo:
         if not self.enable:
             return None, None
         hp = Halo(gq.get(), sp.fold, 0) if gq.get_batch_index() > 0 else None
-        gq.put(self.ex.halo_pack(v[v.shape[0] - 1 - gq.get_future_buffer_length()], sp.fold, sp.fold))
+        last_kept = v.shape[0] - 1 - gq.get_future_buffer_length()
+        if last_kept < 0:          # the reference's x[-1-u] raises IndexError here too (temporal_shift.py:68); never wrap around
+            raise IndexError("segment of %d frame(s) with future_buffer_len %d: no kept frame to queue as the next segment's "
+                             "past slice" % (v.shape[0], gq.get_future_buffer_length()))
+        gq.put(self.ex.halo_pack(v[last_kept], sp.fold, sp.fold))
         return hp, None
 
 
@@ -432,7 +489,7 @@ class TSN(_HipNet):
     (``base_model.nets_list.{0,1}...``), so ``bsvd-64.pth``-style files load with ``load_state_dict`` directly."""
 
     def __init__(self, num_segments=11, base_model='WNet_multistage', shift_type='TSM', shift_div=8, inplace=False,
-                 net2d_opt={}, enable_past_buffer=True, clamp=None, precision='fp32', **kwargs):
+                 net2d_opt={}, enable_past_buffer=True, clamp=None, precision='auto', **kwargs):
         super().__init__()
         if base_model != 'WNet_multistage':
             raise NotImplementedError("base_model %r" % (base_model,))
@@ -441,22 +498,22 @@ class TSN(_HipNet):
         o = dict(chns=[32, 64, 128], mid_ch=3, shift_input=False, stage_num=2, in_ch=4, out_ch=3, norm='bn', act='relu',
                  interm_ch=30, blind=False)
         o.update(net2d_opt)
-        if o['stage_num'] != 2 or o['shift_input'] or o['norm'] != 'none':
-            raise NotImplementedError("TSN on MI355X supports stage_num=2, shift_input=False, norm='none'")
+        if o['stage_num'] != 2 or o['shift_input']:
+            raise NotImplementedError("TSN on MI355X supports stage_num=2, shift_input=False")
         self.num_segments = num_segments
         self.enable_past_buffer = enable_past_buffer
         self._init_engine(make_netspec(o['chns'], o['mid_ch'], o['in_ch'], o['out_ch'], o['act'], o['interm_ch'],
-                                       o['blind']), precision, clamp)
+                                       o['blind']), precision, clamp, o['norm'])
         n = self.net
         stages = []
         for args_ in ((o['in_ch'], o['mid_ch'], o['blind']), (o['mid_ch'], o['out_ch'], False)):
-            blk = _tsn_denblock_params(n.chns, args_[0], args_[1], o['interm_ch'], args_[2])
+            blk = _tsn_denblock_params(n.chns, args_[0], args_[1], o['interm_ch'], args_[2], o['norm'])
             self._reset(blk)                      # wnet_models.DenBlock re-initialises itself, then WNet does (:139,:262)
             stages.append(blk)
         self.base_model = _Slots(nets_list=nn.ModuleList(stages))
         self.reset_params()
 
-    def _engine_state(self):
+    def _bsvd_state(self):
         return checkpoint.to_bsvd_state(self.state_dict())
 
     def forward(self, input, noise_map=None):

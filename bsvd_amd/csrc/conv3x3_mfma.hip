@@ -829,7 +829,20 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
         // waves/SIMD the same tile needs > 256 registers and spills in the main loop: 10x slower.  <4,1,2,2,1,3> for
         // the 64-channel layers: no gain over <2,2,4,1,1,3>.)  Stride 2: single patch buffer -> 3 workgroups/CU
         // instead of 1 (175 -> 287 TFLOP/s).
-        if (!fast_ok(p, false)) { set_error("bsvd_conv3x3: BSVD_F16X3 needs fold %% 16 == 0 (or fold 8 with Cout <= 64) and 16-byte aligned operands"); return -17; }
+        if (!fast_ok(p, false)) {
+            // say WHICH requirement failed: the split kernel has no generic (per-element gather / 64-bit offset) variant
+            if ((int64_t)p.H * p.W * p.Cin * 4 >= 0x7fffffffLL)
+                set_error("bsvd_conv3x3: BSVD_F16X3 addresses one frame with 32-bit byte offsets: H*W*Cin*4 = %lld bytes >= 2 GiB "
+                          "(%d x %d x %d channels); tile the frame spatially or use BSVD_F32, whose generic path has 64-bit offsets",
+                          (long long)((int64_t)p.H * p.W * p.Cin * 4), p.H, p.W, p.Cin);
+            else if ((int64_t)p.Cin * 9 * p.Cout * 4 >= 0x7fffffffLL)
+                set_error("bsvd_conv3x3: BSVD_F16X3 packed weights of %d x %d channels exceed 2 GiB", p.Cin, p.Cout);
+            else if (!p.vec_ok)
+                set_error("bsvd_conv3x3: BSVD_F16X3 needs 16-byte aligned x / halo pointers and strides that are multiples of 4 elements");
+            else
+                set_error("bsvd_conv3x3: BSVD_F16X3 needs fold %% 16 == 0 (or fold 8 with Cout <= 64), got fold %d with Cout %d", p.fold, p.Cout);
+            return -17;
+        }
 #ifndef BSVD_TUNE_S2_SPLIT
 #define BSVD_TUNE_S2_SPLIT 0       // 0: 8x16-px tile, single patch buffer; 1: 4x16-px tile, double-buffered
 #endif

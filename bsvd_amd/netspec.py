@@ -58,6 +58,25 @@ class ConvSpec:
         return self.cin * self.cout * 9 * ho * wo
 
 
+def norm_key_after(conv_key):
+    """state_dict prefix of the normalisation layer that follows conv ``conv_key`` in the reference when norm != 'none'
+    (InputCvBlock convblock.1/.4, DownBlock convblock.1, MemCvBlock b1/b2, OutputCvBlock convblock.1; the UpBlock conv
+    and the exit conv have none: bsvd_arch.py:122-130, 207-216, 237-241, 263-267, 294-298), else None."""
+    stage, block, tail = conv_key.split(".", 2)
+    base = "%s.%s." % (stage, block)
+    if tail == "memconv.c1.op.conv":
+        return base + "memconv.b1"
+    if tail == "memconv.c2.op.conv":
+        return base + "memconv.b2"
+    if block == "inc" and tail == "convblock.0":
+        return base + "convblock.1"
+    if block == "inc" and tail == "convblock.3":
+        return base + "convblock.4"
+    if tail == "convblock.0" and (block.startswith("downc") or block == "outc"):
+        return base + "convblock.1"
+    return None
+
+
 def denblock_specs(pre, chns, in_ch, out_ch, interm_ch, act, blind=False):
     """Ordered {name: ConvSpec} for one DenBlock with state_dict prefix ``pre`` ('temp1.'/'temp2.')."""
     c0, c1, c2 = chns

@@ -48,8 +48,32 @@ def _act(x, kind):
     raise ValueError(kind)
 
 
+def _norm_key(key):
+    """state_dict prefix of the normalisation layer the reference puts right after conv `key` (norm != 'none'), or None:
+    InputCvBlock convblock.1/.4 (bsvd_arch.py:207-216), DownBlock convblock.1 (:237-241), MemCvBlock b1/b2 (:122-130),
+    OutputCvBlock convblock.1 (:294-298); the UpBlock conv and the last conv have none (:263-267, :298)."""
+    parts = key.split(".", 2)
+    if len(parts) < 3:                      # a bare conv (single-layer fixtures): no block structure, no norm layer
+        return None
+    blk, tail = parts[1], parts[2]
+    pre = key[:len(key) - len(tail)]
+    if tail in ("memconv.c1.op.conv", "memconv.c2.op.conv"):
+        return pre + "memconv.b" + tail[9]
+    if blk == "inc" and tail in ("convblock.0", "convblock.3"):
+        return pre + "convblock.%d" % (int(tail[-1]) + 1)
+    if (blk.startswith("downc") or blk == "outc") and tail == "convblock.0":
+        return pre + "convblock.1"
+    return None
+
+
 def _conv(x, P, key, stride=1):
-    return F.conv2d(x, P[key + ".weight"], P[key + ".bias"], stride=stride, padding=1)
+    y = F.conv2d(x, P[key + ".weight"], P[key + ".bias"], stride=stride, padding=1)
+    nk = _norm_key(key)
+    if nk is not None and nk + ".running_mean" in P:
+        # eval-mode nn.BatchNorm2d (get_norm_function 'bn', bsvd_arch.py:176-183): running statistics, eps 1e-5
+        y = F.batch_norm(y, P[nk + ".running_mean"], P[nk + ".running_var"], P[nk + ".weight"], P[nk + ".bias"],
+                         training=False, eps=1e-5)
+    return y
 
 
 def _ps2(x):

@@ -130,7 +130,7 @@ def import_reference_callers():
 def load_seeded(module, seed):
     sd = module.state_dict()
     st = seeded_state([(k, tuple(v.shape)) for k, v in sd.items()], seed)
-    module.load_state_dict(OrderedDict((k, torch.from_numpy(v)) for k, v in st.items()))
+    module.load_state_dict(OrderedDict((k, torch.from_numpy(np.asarray(v))) for k, v in st.items()))
     return st
 
 
@@ -513,6 +513,21 @@ def ndimage_smooth(a):
     return ndimage.uniform_filter(a, size=(5, 5, 1), mode="nearest") * 1.6 - 60.0
 
 
+def g13_batchnorm_defaults(ref):
+    """The reference constructor's TRUE defaults -- norm='bn' (bsvd_arch.py:446, get_norm_function :176-183), mid_ch 3,
+    interm_ch 30, ReLU -- in eval mode with non-trivial BatchNorm affine parameters and running statistics: what an
+    eval-mode BatchNorm fold into the packed conv weights has to reproduce."""
+    seed = 1301
+    net = ref.BSVD(pretrain_ckpt=None)
+    net.eval()
+    st = load_seeded(net, seed)
+    x = seeded_clip((1, 4, 4, 16, 20), seed + 1, kind="sigma30")
+    with torch.no_grad():
+        y = net(torch.from_numpy(x))
+    save("g13_batchnorm_defaults", x=x, out=t2n(y), seed=np.int64(seed), digest=np.array(state_digest(st)),
+         keys=np.array(list(st.keys())))
+
+
 def g10_mimo_segments():
     """MIMO / segmented inference of the reference: TSN (eval) driven by denoise_seq with temp_psz < T, look-ahead
     frames and the global past-slice queue (validation_seq_infer.py:33-100, temporal_shift.py:53-80,
@@ -582,6 +597,7 @@ def main(out_dir=None):
     g10_mimo_segments()
     g11_seeded_init()
     g12_ssim()
+    g13_batchnorm_defaults(ref)
 
 
 if __name__ == "__main__":

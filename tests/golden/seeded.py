@@ -18,7 +18,18 @@ def seeded_state(named_shapes, seed):
     out = OrderedDict()
     for key, shape in named_shapes:
         shape = tuple(int(s) for s in shape)
-        if key.endswith(".weight"):
+        # BatchNorm2d tensors (norm='bn' networks): affine, running statistics and the step counter of a "trained" layer
+        if key.endswith(".running_mean"):
+            out[key] = (rs.standard_normal(shape) * 0.2).astype(np.float32)
+        elif key.endswith(".running_var"):
+            out[key] = rs.uniform(0.5, 1.5, size=shape).astype(np.float32)
+        elif key.endswith(".num_batches_tracked"):
+            out[key] = np.array(7, dtype=np.int64)
+        elif key.endswith(".weight") and len(shape) == 1:
+            out[key] = rs.uniform(0.5, 1.5, size=shape).astype(np.float32)
+        elif key.endswith(".bias") and len(next(reversed(out.values())).shape) == 1:
+            out[key] = rs.uniform(-0.2, 0.2, size=shape).astype(np.float32)
+        elif key.endswith(".weight"):
             fan_in = shape[1] * shape[2] * shape[3]
             out[key] = (rs.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
         elif key.endswith(".bias"):

@@ -77,7 +77,11 @@ def test_variant_dry_run_reports_dispatch():
     assert variant(dtype=_lib.BSVD_F16X3, frames=1) == (0, "conv3x3_kernel<2,2,2,2,1>[f16x3]")     # small grid: thin tiles
     assert variant(Cout=64, H=540, W=960, Cin=64) == (0, "conv3x3_kernel<2,2,4,1,1>[f32]")
     assert variant(stride=2, Cin=64) == (0, "conv3x3_kernel<2,2,2,2,2>[f32]")
-    assert variant(dtype=_lib.BSVD_F16X3, fold=12)[0] == -17
+    assert variant(dtype=_lib.BSVD_F16X3, fold=12)[0] == -17 and b"fold 12" in lib.bsvd_last_error()
+    # a frame of 2 GiB or more cannot be addressed by the split kernel: the error says so (not "fold")
+    assert variant(dtype=_lib.BSVD_F16X3, frames=1, H=4320, W=7680, Cin=64, Cout=64)[0] == -17
+    assert b"2 GiB" in lib.bsvd_last_error() and b"4320 x 7680" in lib.bsvd_last_error()
+    assert variant(frames=1, H=4320, W=7680, Cin=64, Cout=64) == (0, "conv3x3_kernel<2,2,4,1,1>[f32][generic]")
     assert variant(Cin=12)[0] == -5
 
 
@@ -87,7 +91,7 @@ def test_product_has_no_cpu_fallback():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     import bsvd_amd
-    m = bsvd_amd.BSVD(norm="none", pretrain_ckpt=None)
+    m = bsvd_amd.BSVD(precision="fp32", norm="none", pretrain_ckpt=None)
     with pytest.raises(RuntimeError, match="HIP device"):
         m(torch.zeros(1, 2, 4, 8, 8))
     with pytest.raises(RuntimeError, match="HIP device"):

@@ -68,3 +68,81 @@ def test_shard_range_covers_clip():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_device_buffer_branch_of_halo_exchange_with_a_stub_backend(monkeypatch):
+    """The RCCL branch of HaloExchanger (host_staging False: the backend gets the packed slices / receive buffers
+    themselves, finish() only waits) cannot run without two GPUs; its bookkeeping can.  A stub point-to-point fabric
+    stands in for torch.distributed: sends and receives are matched by (source, destination) in posting order, the
+    payload moves when the RECEIVER's request is waited on, and every wait() is logged.  Two shards of one clip are then
+    driven through schedule.bsvd_clip's overlapped form (start -> interior frames -> finish -> boundary frames)."""
+    import collections
+    import bsvd_amd.dist as D
+    from oracle_exec import OracleExecutor
+    from bsvd_amd.netspec import make_netspec
+    from bsvd_amd.schedule import Halo
+
+    mailbox = collections.defaultdict(collections.deque)        # (src, dst) -> sent tensors
+    log = []
+
+    class Op:
+        def __init__(self, op, tensor, peer, group=None):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    class Req:
+        def __init__(self, kind, me, op):
+            self.kind, self.me, self.op, self.done = kind, me, op, False
+
+        def wait(self):
+            log.append((self.me, self.kind, self.op.peer))
+            if self.kind == "recv":
+                src = mailbox[(self.op.peer, self.me)].popleft()
+                assert src.shape == self.op.tensor.shape
+                self.op.tensor.copy_(src)
+            self.done = True
+
+    current = {"rank": None}
+
+    def batch(ops):
+        reqs = []
+        for o in ops:
+            if o.op == "isend":
+                assert o.tensor.is_contiguous()
+                mailbox[(current["rank"], o.peer)].append(o.tensor)     # NOT cloned: `keep` must pin it until finish()
+                reqs.append(Req("send", current["rank"], o))
+            else:
+                reqs.append(Req("recv", current["rank"], o))
+        return reqs
+
+    monkeypatch.setattr(D.dist, "get_backend", lambda group=None: "nccl")
+    monkeypatch.setattr(D.dist, "P2POp", Op)
+    monkeypatch.setattr(D.dist, "isend", "isend")
+    monkeypatch.setattr(D.dist, "irecv", "irecv")
+    monkeypatch.setattr(D.dist, "batch_isend_irecv", batch)
+
+    g = load_golden("g4_bsvd_small_T7")
+    st = state_for(g, bsvd_keys([32, 64, 128], 32, 4, 3, 32))
+    net = make_netspec([32, 64, 128], 32, 4, 3, "relu6", 32)
+    sp = net.temp1["d0c1"]
+    ex = OracleExecutor(st)
+    torch.manual_seed(3)
+    v = torch.rand(6, 8, 12, sp.cin_pad)
+    whole = ex.conv(sp, v)
+    hx = [D.HaloExchanger(ex, r, 2) for r in (0, 1)]
+    assert not hx[0].host_staging
+    shards = [v[:3].contiguous(), v[3:].contiguous()]
+    pend = []
+    for r in (0, 1):
+        current["rank"] = r
+        pend.append(hx[r].start(sp, shards[r]))
+    assert not log, "start() must not wait"
+    assert all(p.staged == [] and len(p.keep) == 1 for p in pend)
+    outs = []
+    for r in (0, 1):
+        hp, hn = pend[r].finish()
+        assert [e for e in log if e[0] == r] == [(r, "send", 1 - r), (r, "recv", 1 - r)]
+        assert pend[r].keep == ()
+        assert (hp is None) == (r == 0) and (hn is None) == (r == 1)
+        outs.append(ex.conv(sp, shards[r], halo_prev=hp, halo_next=hn))
+    assert torch.equal(torch.cat(outs), whole)
+    assert hx[0].bytes_sent == 8 * 12 * sp.fold * 4 and hx[0].exchanges == 1

@@ -96,10 +96,10 @@ def test_seeded_construction_matches_reference_rng_stream():
     from bsvd_amd.arch import TSN
     g = load_golden("g11_seeded_init")
     torch.manual_seed(123)
-    m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, norm="none", act="relu6", interm_ch=64, pretrain_ckpt=None)
+    m = bsvd_amd.BSVD(precision="fp32", chns=[64, 128, 256], mid_ch=64, norm="none", act="relu6", interm_ch=64, pretrain_ckpt=None)
     assert state_digest(OrderedDict((k, v.numpy()) for k, v in m.state_dict().items())) == str(g["bsvd_digest"])
     assert np.array_equal(torch.rand(4).numpy(), g["bsvd_next"])
     torch.manual_seed(321)
-    t = TSN(num_segments=11, net2d_opt=dict(chns=[64, 128, 256], mid_ch=64, norm="none", act="relu", interm_ch=30, blind=True))
+    t = TSN(precision="fp32", num_segments=11, net2d_opt=dict(chns=[64, 128, 256], mid_ch=64, norm="none", act="relu", interm_ch=30, blind=True))
     assert state_digest(OrderedDict((k, v.numpy()) for k, v in t.state_dict().items())) == str(g["tsn_digest"])
     assert np.array_equal(torch.rand(4).numpy(), g["tsn_next"])

@@ -72,7 +72,7 @@ def test_run_test_counterpart_end_to_end(tmp_path):
     # oracle pipeline with the same RNG stream: seed -> model construction (consumes RNG) -> per-clip noise in sorted order
     import bsvd_amd
     torch.manual_seed(10)
-    bsvd_amd.BSVD(chns=[32, 64, 128], mid_ch=32, norm="none", interm_ch=32, act="relu6", pretrain_ckpt=None)
+    bsvd_amd.BSVD(precision="fp32", chns=[32, 64, 128], mid_ch=32, norm="none", interm_ch=32, act="relu6", pretrain_ckpt=None)
     P = O.to_torch_state(st)
     cfg = O.default_cfg(chns=[32, 64, 128], mid_ch=32, interm_ch=32)
     for clip in ("clipA", "clipB"):

@@ -150,7 +150,7 @@ def test_layout_roundtrip_and_clamp():
 
 def _module(chns, mid_ch, interm_ch, act, st, blind=False, mode="clip"):
     import bsvd_amd
-    m = bsvd_amd.BSVD(chns=chns, mid_ch=mid_ch, in_ch=4, out_ch=3, norm="none", act=act, interm_ch=interm_ch,
+    m = bsvd_amd.BSVD(precision="fp32", chns=chns, mid_ch=mid_ch, in_ch=4, out_ch=3, norm="none", act=act, interm_ch=interm_ch,
                       blind=blind, pretrain_ckpt=None, engine_mode=mode)
     m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
     return m.to(_dev())
@@ -362,7 +362,7 @@ def test_tsn_segmented_inference_on_gpu(tag):
     g = load_golden("g10_mimo_segments")
     st = seeded_state([(str(k), tuple(int(v) for v in str(s_).split(","))) for k, s_ in zip(g["tsn_keys"], g["tsn_shapes"])],
                       int(g["seed"]))
-    m = TSN(num_segments=3, net2d_opt=dict(chns=[32, 64, 128], mid_ch=32, in_ch=4, out_ch=3, norm="none", act="relu6",
+    m = TSN(precision="fp32", num_segments=3, net2d_opt=dict(chns=[32, 64, 128], mid_ch=32, in_ch=4, out_ch=3, norm="none", act="relu6",
                                            interm_ch=32, blind=False))
     m.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
     m = m.to(_dev()).eval()
@@ -417,7 +417,7 @@ def test_half_io_like_profile_py():
     import bsvd_amd
     from oracle import bsvd_oracle as O
     st = seeded_state(bsvd_keys([64, 128, 256], 64, 4, 3, 64), 53)
-    m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, norm="none", act="relu6", interm_ch=64, pretrain_ckpt=None)
+    m = bsvd_amd.BSVD(precision="fp32", chns=[64, 128, 256], mid_ch=64, norm="none", act="relu6", interm_ch=64, pretrain_ckpt=None)
     m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
     m = m.to(_dev()).half().eval()
     x = torch.randn(1, 3, 4, 16, 24).half()
@@ -485,7 +485,7 @@ def test_rejects_bad_arguments():
     assert lib.bsvd_conv3x3(ctypes.byref(a), None) < 0
     assert b"non-NULL" in lib.bsvd_last_error()
     import bsvd_amd
-    m = bsvd_amd.BSVD(norm="none", pretrain_ckpt=None).to(_dev())
+    m = bsvd_amd.BSVD(precision="fp32", norm="none", pretrain_ckpt=None).to(_dev())
     with pytest.raises(ValueError):
         m(torch.zeros(1, 2, 4, 18, 26, device=_dev()))     # not a multiple of 4 (reference fails at the skip add)
     with pytest.raises(ValueError):

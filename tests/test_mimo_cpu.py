@@ -36,7 +36,7 @@ def _net(g):
     st = seeded_state([(str(k), tuple(int(v) for v in str(s).split(","))) for k, s in zip(g["tsn_keys"], g["tsn_shapes"])],
                       int(g["seed"]))
     assert state_digest(st) == str(g["digest"])
-    m = CpuTSN(num_segments=3, net2d_opt=dict(chns=[32, 64, 128], mid_ch=32, in_ch=4, out_ch=3, norm="none", act="relu6",
+    m = CpuTSN(precision="fp32", num_segments=3, net2d_opt=dict(chns=[32, 64, 128], mid_ch=32, in_ch=4, out_ch=3, norm="none", act="relu6",
                                              interm_ch=32, blind=False))
     m.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})      # TSN schema, strict
     return m.eval()
@@ -66,7 +66,7 @@ def test_queue_module_surface():
 
 def test_tsn_rejects_unsupported_variants():
     with pytest.raises(NotImplementedError):
-        TSN(shift_type="TSM_toFutureOnly", net2d_opt=dict(norm="none"))
+        TSN(precision="fp32", shift_type="TSM_toFutureOnly", net2d_opt=dict(norm="none"))
     with pytest.raises(NotImplementedError):
-        TSN(net2d_opt=dict(norm="bn"))
+        TSN(precision="fp32", net2d_opt=dict(norm="in"))
     assert "TSN" in bsvd_amd.ARCH_REGISTRY or "TSN_MI355X" in bsvd_amd.ARCH_REGISTRY

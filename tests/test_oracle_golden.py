@@ -170,3 +170,17 @@ def test_g7_ckpt_keymap():
     # and without the DataParallel prefix
     k0 = str(g["tsn_keys"][6])
     assert next(iter(O.tsn_to_bsvd_keys({k0: 0}))) == str(g["bsvd_keys"][6])
+
+
+def test_g13_batchnorm_defaults():
+    """The reference constructor's true defaults (norm='bn', eval mode): oracle with explicit eval-mode batch_norm."""
+    g = load_golden("g13_batchnorm_defaults")
+    st = state_for(g, bsvd_keys([32, 64, 128], 3, 4, 3, 30, norm="bn"))
+    assert list(st.keys()) == list(g["keys"])
+    P = O.to_torch_state(st)
+    cfg = O.default_cfg(chns=[32, 64, 128], mid_ch=3, act="relu", interm_ch=30)
+    scale = float(np.abs(g["out"]).max())
+    y = O.bsvd_clip(torch.from_numpy(g["x"]), P, cfg)
+    assert maxabs(y.numpy(), g["out"]) < 1e-5 * scale
+    y = O.stream_forward(torch.from_numpy(g["x"]), P, cfg)
+    assert maxabs(y.numpy(), g["out"]) < 1e-5 * scale

@@ -213,3 +213,42 @@ def test_clip_peak_bytes_bound():
     bsvd_clip(ex, small, x)
     assert 0 < peak[0] <= clip_peak_bytes(small, T, H, W)
     print('live peak %d B, bound %d B' % (peak[0], clip_peak_bytes(small, T, H, W)))
+
+
+def test_batchnorm_fold_reproduces_the_reference_default_constructor():
+    """norm='bn' (the reference's default ctor, bsvd_arch.py:446): the product folds the eval-mode BatchNorm layers into
+    the packed conv weights (checkpoint.fold_batchnorm); the folded network through the schedules equals the reference."""
+    import bsvd_amd
+    from bsvd_amd.netspec import norm_key_after
+    g = load_golden("g13_batchnorm_defaults")
+    st = state_for(g, bsvd_keys([32, 64, 128], 3, 4, 3, 30, norm="bn"))
+    m = bsvd_amd.BSVD(pretrain_ckpt=None)                       # all defaults, like the reference's BSVD()
+    assert m.norm == "bn" and sorted(m.state_dict().keys()) == sorted(st.keys())
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()})
+    with pytest.raises(RuntimeError, match="eval"):
+        m._executor(torch.device("cpu"))                         # train mode: batch statistics cannot be folded
+    folded = {k: v.numpy() for k, v in m.eval()._engine_state().items()}
+    assert len(folded) == 64 and not any(".b1." in k or "running" in k for k in folded)
+    assert norm_key_after("temp1.upc2.convblock.0") is None and norm_key_after("temp2.outc.convblock.3") is None
+    assert norm_key_after("temp2.downc1.memconv.c2.op.conv") == "temp2.downc1.memconv.b2"
+    scale = float(np.abs(g["out"]).max())
+    y, _ = run_clip(m.net, folded, g["x"])
+    assert maxabs(y, g["out"]) < 2e-5 * scale
+    y, _ = run_stream(m.net, folded, g["x"])
+    assert maxabs(y, g["out"]) < 2e-5 * scale
+    # an in-place update of a running statistic re-packs (signature covers buffers)
+    sig = m._signature()
+    m.temp1.inc.convblock["1"].running_mean.add_(0.5)
+    assert m._signature() != sig
+    with pytest.raises(NotImplementedError):
+        bsvd_amd.BSVD(norm="in", pretrain_ckpt=None)
+
+
+def test_precision_auto_picks_split_when_the_network_admits_it():
+    import bsvd_amd
+    assert bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, norm="none", act="relu6", interm_ch=64, pretrain_ckpt=None).precision == "f16x3"
+    assert bsvd_amd.BSVD(norm="none", pretrain_ckpt=None).precision == "f16x3"          # c32-sized: fold 8 / 16
+    odd = bsvd_amd.BSVD(chns=[16, 32, 64], mid_ch=16, norm="none", interm_ch=16, pretrain_ckpt=None)
+    assert odd.precision == "fp32" and odd.precision_requested == "auto"                # fold 4 / 8 on 32 / 64 channels... not admitted
+    with pytest.raises(ValueError):
+        bsvd_amd.BSVD(chns=[16, 32, 64], mid_ch=16, norm="none", interm_ch=16, pretrain_ckpt=None, precision="f16x3")
