@@ -173,11 +173,54 @@ static void case_split_chain() {
     report("split-fp16 chain: planar in -> 4->64 -> 64->64 (f16x3) -> 64->3 resid+clamp", maxabs(got, want), 1e-3);
 }
 
+// One streaming step as one submission (ABI v6): the three-layer split chain issued with bsvd_conv3x3_batch, then captured
+// into a HIP graph on a created stream and replayed on another; both must reproduce the layer-by-layer result bit for bit.
+static void case_batch_and_graph() {
+    const int T = 1, H = 24, W = 40, C = 64;
+    auto x = randv((size_t)T * 4 * H * W, 1.f);
+    auto w1 = randv((size_t)C * 4 * 9, 0.3f), b1 = randv(C, 0.1f);
+    auto w2 = randv((size_t)C * C * 9, 0.06f), b2 = randv(C, 0.1f);
+    auto w3 = randv((size_t)3 * C * 9, 0.06f), b3 = randv(3, 0.1f);
+    float *dx = dev(x), *d1 = dev_zeros((size_t)T * H * W * C), *d2 = dev_zeros((size_t)T * H * W * C), *dy = dev_zeros((size_t)T * 3 * H * W);
+    Packed p1 = pack(w1, b1, 4, C, 16, C, 0, BSVD_F32), p2 = pack(w2, b2, C, C, C, C, 0, BSVD_F16X3), p3 = pack(w3, b3, C, 3, C, 16, 0, BSVD_F16X3);
+    BsvdConvArgs a[3]; memset(a, 0, sizeof(a));
+    a[0].x = dx; a[0].x_frame_stride = (int64_t)4 * H * W; a[0].x_planar_ch = 4; a[0].w_packed = p1.w; a[0].bias_packed = p1.b;
+    a[0].y = d1; a[0].y_frame_stride = (int64_t)H * W * C; a[0].Cin = 16; a[0].Cout = C; a[0].act = BSVD_ACT_RELU6;
+    a[1].x = d1; a[1].x_frame_stride = (int64_t)H * W * C; a[1].w_packed = p2.w; a[1].bias_packed = p2.b; a[1].y = d2;
+    a[1].y_frame_stride = (int64_t)H * W * C; a[1].Cin = C; a[1].Cout = C; a[1].act = BSVD_ACT_RELU6;
+    a[2].x = d2; a[2].x_frame_stride = (int64_t)H * W * C; a[2].w_packed = p3.w; a[2].bias_packed = p3.b; a[2].y = dy;
+    a[2].y_frame_stride = (int64_t)3 * H * W; a[2].extra = dx; a[2].extra_frame_stride = (int64_t)4 * H * W; a[2].extra_pstride = 1;
+    a[2].extra_cstride = H * W; a[2].resid_ch = 3; a[2].Cin = C; a[2].Cout = 16; a[2].act = BSVD_ACT_NONE; a[2].epilogue = BSVD_EPI_RESID; a[2].y_planar_ch = 3;
+    for (auto &l : a) { l.frames = T; l.H = H; l.W = W; l.stride = 1; l.dtype = BSVD_F16X3; }
+    for (auto &l : a) ABI_OK(bsvd_conv3x3(&l, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    auto ref = host(dy, (size_t)T * 3 * H * W);
+    HIP_OK(hipMemset(dy, 0, sizeof(float) * T * 3 * H * W));
+    ABI_OK(bsvd_conv3x3_batch(a, 3, nullptr)); HIP_OK(hipDeviceSynchronize());
+    auto got = host(dy, (size_t)T * 3 * H * W);
+    report("bsvd_conv3x3_batch == three bsvd_conv3x3 calls (bitwise)", maxabs(got, ref), 1e-30);
+    BsvdConvArgs bad = a[1]; bad.stride = 3;
+    BsvdConvArgs seq[2] = {a[0], bad};
+    if (bsvd_conv3x3_batch(seq, 2, nullptr) != -6 || !strstr(bsvd_last_error(), "layer 1 of 2")) { printf("batch error reporting: %s\n", bsvd_last_error()); ++failures; }
+    hipStream_t cap, run; HIP_OK(hipStreamCreate(&cap)); HIP_OK(hipStreamCreate(&run));
+    if (bsvd_graph_begin(nullptr) != -1) { printf("capture on the default stream must be refused\n"); ++failures; }
+    void *g = nullptr; int32_t nodes = 0;
+    ABI_OK(bsvd_graph_begin(cap)); ABI_OK(bsvd_conv3x3_batch(a, 3, cap)); ABI_OK(bsvd_graph_end(cap, &g, &nodes));
+    if (nodes != 3) { printf("graph has %d nodes, expected 3\n", nodes); ++failures; }
+    for (int rep = 0; rep < 2; ++rep) {
+        HIP_OK(hipMemset(dy, 0, sizeof(float) * T * 3 * H * W));
+        ABI_OK(bsvd_graph_launch(g, run)); HIP_OK(hipStreamSynchronize(run));
+        got = host(dy, (size_t)T * 3 * H * W);
+        report(rep ? "HIP graph replay #2 == direct launches (bitwise)" : "HIP graph replay #1 == direct launches (bitwise)", maxabs(got, ref), 1e-30);
+    }
+    ABI_OK(bsvd_graph_destroy(g)); HIP_OK(hipStreamDestroy(cap)); HIP_OK(hipStreamDestroy(run));
+}
+
 int main() {
     if (bsvd_abi_version() != BSVD_ABI_VERSION || bsvd_conv_args_size() != (int)sizeof(BsvdConvArgs)) { printf("ABI mismatch\n"); return 1; }
     int n = 0; HIP_OK(hipGetDeviceCount(&n)); if (n < 1) { printf("no HIP device\n"); return 1; }
     HIP_OK(hipSetDevice(0));
-    case_tsm(); case_stride2(); case_pixel_shuffle(); case_split_chain();
+    case_tsm(); case_stride2(); case_pixel_shuffle(); case_split_chain(); case_batch_and_graph();
     printf(failures ? "abi_parity: %d FAILED\n" : "abi_parity: all cases ok\n", failures);
     return failures ? 1 : 0;
 }

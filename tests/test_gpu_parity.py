@@ -214,6 +214,33 @@ def test_golden_default_ctor_odd_channels(precision):
     assert torch.equal(m(x[:, :, :3], noise_map=x[:, :, 3:4]), y)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "auto"])
+def test_golden_reference_default_constructor_with_batchnorm(precision):
+    """BSVD() exactly as the reference constructs it by default (norm='bn', bsvd_arch.py:446) in eval mode with non-trivial
+    BatchNorm affine parameters and running statistics (golden g13): folded into the packed conv weights at pack time."""
+    import bsvd_amd
+    g = load_golden("g13_batchnorm_defaults")
+    st = state_for(g, bsvd_keys([32, 64, 128], 3, 4, 3, 30, norm="bn"))
+    m = bsvd_amd.BSVD(pretrain_ckpt=None, precision=precision)
+    m.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in st.items()})
+    m = m.to(_dev())
+    x = torch.from_numpy(g["x"]).to(_dev())
+    with pytest.raises(RuntimeError, match="eval"):
+        m(x)
+    m.eval()
+    assert m.precision == ("fp32" if precision == "fp32" else "f16x3")
+    y = m(x)
+    scale = float(np.abs(g["out"]).max())
+    err = maxabs(y.cpu().numpy(), g["out"])
+    print("BSVD() with norm='bn', %s: max-abs vs golden %.2e at output magnitude %.1f" % (m.precision, err, scale))
+    assert err < (2e-5 if m.precision == "fp32" else 5e-5) * scale
+    m.engine_mode = "stream"
+    assert torch.equal(m(x), y)
+    with torch.no_grad():                           # a changed running statistic re-packs the folded weights
+        m.temp1.inc.convblock["1"].running_mean.add_(0.25)
+    assert not torch.equal(m(x), y)
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_golden_c64(tag):
     g = load_golden("g5_bsvd_c64_" + tag)
