@@ -204,6 +204,13 @@ struct ChunkSrc {          // wave-uniform description of one 16-channel chunk's
 #ifndef BSVD_TUNE_S2_GROUP
 #define BSVD_TUNE_S2_GROUP 1       // slices per round trip of the split-fp16 stride-2 patch refill
 #endif
+#ifndef BSVD_TUNE_S2_PAIR
+#define BSVD_TUNE_S2_PAIR 0        // 1: split-fp16 stride-2 tile fetches BOTH 16-channel chunks of a 128-byte line in one go (odd chunk held in
+                                   // registers, one round trip per two chunks).  Measured r02: bit-identical, but the 36 extra VGPRs cost the third
+                                   // wave per SIMD and the kernel gets SLOWER (2.61 vs 2.41 ms per clip): occupancy, not the re-fetched lines, is
+                                   // what this tile lives on (the re-fetches are largely served by the 256 MiB Infinity Cache, which the EA counters
+                                   // cannot tell from HBM)
+#endif
 #ifndef BSVD_TUNE_FILL
 #define BSVD_TUNE_FILL 1           // 1: the whole LDS patch of a prologue / single-buffer refill in flight at once
 #endif
@@ -212,6 +219,8 @@ constexpr int occ_of()
 {
     // exact-fp32 stride 2 (single patch buffer): the refill holds the whole 17x33 patch in registers (72 VGPRs) -> 2 waves/SIMD
     if (C::STRIDE == 2 && PREC == 0 && C::OCC > BSVD_TUNE_S2F32_OCC) return BSVD_TUNE_S2F32_OCC;
+    // split-fp16 single-buffer tile with the odd chunk of every 128-byte line held in registers (72 VGPRs): 2 waves/SIMD
+    if (!C::DBUF && PREC == 1 && BSVD_TUNE_S2_PAIR && C::OCC > 2) return 2;
     return C::OCC;
 }
 
@@ -434,7 +443,55 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     if (g0 + sl < C::NSLICE) slice_store(pb, (g0 + sl) * C::ROWS_PER_SLICE, v[sl]);
             }
         };
-        fill_patch(chunk_src(0), patch_buf);
+        // Single-buffer split tile (stride 2), PAIR mode.  A 128-byte L2 line holds TWO 16-channel chunks of a pixel.  Fetched one
+        // chunk per boundary, the line is gone from the 4 MiB L2 by the time its second half is wanted (96 resident workgroups
+        // per XCD x 561-pixel patches = 6.9 MB of lines in flight): the PMC passes showed 2.04x the input bytes at the memory
+        // side and the 64->128 layer running at 5.1 TB/s, i.e. HBM-bound on re-fetches.  So every even boundary requests both
+        // halves of each line back to back -- the even chunk goes to LDS, the odd one waits in registers (hold, 72 VGPRs) and
+        // is published at the next boundary without touching memory.
+        constexpr bool PAIR = !C::DBUF && PREC == 1 && BSVD_TUNE_S2_PAIR;
+        // PAIR items: the patch flattened to (row, column, 16-byte quad) items, 256 per pass -- the row-slice map above keeps
+        // only 132 of 256 lanes busy on the 33-pixel rows of this tile, which would double the registers the held chunk costs
+        constexpr int PNITEM = C::PH * C::ROW_ITEMS, PNI = (PNITEM + 255) / 256;
+        [[maybe_unused]] f32x4 hold[PAIR ? PNI : 1];
+        auto pair_item = [&](int i, unsigned &voff, int &lds_off, bool &in_patch) {
+            const int e = tid + 256 * i;
+            const int prow = e / C::ROW_ITEMS, rem = e - prow * C::ROW_ITEMS;
+            const int pc = rem >> 2, pq4 = rem & 3;
+            const int gy = iy0 + prow, gxx = ix0 + pc;
+            in_patch = e < PNITEM;
+            const bool ok = in_patch && gy >= 0 && gy < p.H && gxx >= 0 && gxx < p.W;
+            voff = ok ? (unsigned)(gy * p.W + gxx) * ((unsigned)p.Cin * 4u) + pq4 * 16u : BSVD_OOB;
+            lds_off = prow * C::ROWP + pc * C::PS + pq4 * 4;
+        };
+        auto fill_pair = [&](int cbe, float *pb) {      // stride-2 layers are plain convs: every chunk comes from the frame itself
+            const unsigned so_e = (unsigned)cbe * 64u;
+            const __amdgpu_buffer_rsrc_t rs_o = cbe + 1 < ncb ? rs_cur : make_rsrc(s.cur, 0u);   // no odd partner: zeros, never used
+            f32x4 v[PNI];
+#pragma unroll
+            for (int i = 0; i < PNI; ++i) {
+                unsigned voff; int lo; bool inp;
+                pair_item(i, voff, lo, inp);
+                v[i] = buf_load4(rs_cur, voff, so_e);
+                if constexpr (PAIR) hold[i] = buf_load4(rs_o, voff, so_e + 64u);
+            }
+#pragma unroll
+            for (int i = 0; i < PNI; ++i) {
+                unsigned voff; int lo; bool inp;
+                pair_item(i, voff, lo, inp);
+                if (inp) *reinterpret_cast<f32x4 *>(pb + lo) = v[i];
+            }
+        };
+        auto publish_hold = [&](float *pb) {
+#pragma unroll
+            for (int i = 0; i < PNI; ++i) {
+                unsigned voff; int lo; bool inp;
+                pair_item(i, voff, lo, inp);
+                if constexpr (PAIR) if (inp) *reinterpret_cast<f32x4 *>(pb + lo) = hold[i];
+            }
+        };
+        if constexpr (PAIR) fill_pair(0, patch_buf);
+        else fill_patch(chunk_src(0), patch_buf);
         __syncthreads();
         TL(1);
 
@@ -494,7 +551,17 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
             }
             __syncthreads();   // one barrier per 16-channel chunk (9 taps, 288 MFMAs per wave)
             if constexpr (!C::DBUF) {
-                if (cb + 1 < ncb) fill_patch(cn, patch_buf);   // single buffer: everybody is done reading it -> refill, publish
+                if (cb + 1 < ncb) {        // single buffer: everybody is done reading it -> refill, publish
+                    if constexpr (PAIR) {
+                        if ((cb + 1) & 1) {
+                            publish_hold(patch_buf);
+                        } else {
+                            fill_pair(cb + 1, patch_buf);
+                        }
+                    } else {
+                        fill_patch(cn, patch_buf);
+                    }
+                }
                 __syncthreads();
             }
         }
@@ -616,9 +683,10 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
             }
         }
     float *sc = smem + wid * (32 * 36);
-    auto finish = [&](auto epi_c, auto act_c) {
+    auto finish = [&](auto epi_c, auto act_c, auto psf_c) {
         constexpr int EPI = decltype(epi_c)::value, ACT = decltype(act_c)::value;
-        struct Item { bool live; int64_t opix; int n8, c8; float *dst; };
+        constexpr bool PSF = decltype(psf_c)::value;      // PixelShuffle items with wave-uniform sub-pixel / channel base
+        struct Item { bool live; int64_t opix; int n8, c8; float *dst; const float *esrc; };
         // PLAIN / RESID: everything that depends on the lane is computed once; an item only adds compile-time multiples of
         // the (wave-uniform) row stride -- every instruction of a finishing wave waits for a gap between the co-resident
         // wave's MFMAs, so per-item 64-bit address arithmetic was a measurable part of the epilogue
@@ -629,10 +697,49 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         const int64_t rowstride = (int64_t)p.Wo * p.Cout;
         float *const l_base = p.y + (int64_t)f * p.y_fs + l_pix * p.Cout +
                               (PREC == 1 ? (l_ch >> 4) * 16 + ((l_ch >> 3) & 1) * 4 : l_ch);
+        // PixelShuffle items of the split mode, Cq % 32 == 0 (every c64 / c32-sized network): a 32-channel MFMA tile lies inside
+        // ONE sub-pixel plane, so the sub-pixel, the channel base and the row are wave-uniform and an item's address is
+        // (lane part, computed once) + (scalar part).  The generic form below divides by Cq and does 64-bit multiplies per
+        // lane and item: 150-230 instructions per item against 60 here -- each of them waits for a gap between the
+        // co-resident wave's MFMAs (the 128->256 layer ran 12 % below the temporal-fusion layers of the same shape).
+        [[maybe_unused]] int ps_sub0 = 0, ps_rem0 = 0, ps_r[C::NT] = {}, ps_sub[C::NT] = {};
+        [[maybe_unused]] float *ps_ybase = nullptr;
+        [[maybe_unused]] const float *ps_ebase = nullptr;
+        if constexpr (PSF) {
+            ps_sub0 = n0 / Cq;
+            ps_rem0 = n0 - ps_sub0 * Cq;
+            const int lq = (q >> 1) * 16 + (q & 1) * 4;              // this lane's 8-channel piece inside a 32-channel tile
+            const int64_t lpix = (int64_t)(2 * l_oy) * (2 * p.Wo) + 2 * l_ox;
+            ps_ybase = p.y + (int64_t)f * p.y_fs + lpix * Cq + lq;
+            ps_ebase = p.extra ? p.extra + (int64_t)f * p.extra_fs + lpix * p.extra_ps + lq : nullptr;
+#pragma unroll
+            for (int nt = 0; nt < C::NT; ++nt) {                     // sub-pixel plane and channel base of each 32-channel tile
+                int r = ps_rem0 + wn * (C::NT * 32) + nt * 32, sub = ps_sub0;
+                while (r >= Cq) { r -= Cq; ++sub; }
+                ps_r[nt] = r;
+                ps_sub[nt] = sub;
+            }
+        }
         auto item_of = [&](int i) {          // i = ((mt * NT + nt) * 2 + s), compile-time after unrolling
             const int sidx = i & 1, nt = (i >> 1) % C::NT, mt = (i >> 1) / C::NT;
             int oy, ox;
             Item t;
+            t.esrc = nullptr;
+            if constexpr (PSF) {
+                {
+                    const int off = wn * (C::NT * 32) + nt * 32;                     // wave-uniform
+                    const int r = ps_r[nt], sub = ps_sub[nt];
+                    const int row = 2 * mt + sidx;                                   // conv-output rows below l_oy
+                    const int64_t upix = (int64_t)(2 * row + (sub >> 1)) * (2 * p.Wo) + (sub & 1);
+                    t.n8 = n0 + off + 8 * q;
+                    t.c8 = r + 8 * q;
+                    t.live = l_oy + row < p.Ho && l_ox < p.Wo && n0 + off < p.Cout;
+                    t.opix = 0;
+                    t.dst = ps_ybase + upix * Cq + r;
+                    t.esrc = ps_ebase ? ps_ebase + upix * p.extra_ps + r : nullptr;
+                    return t;
+                }
+            }
             if constexpr (EPI != BSVD_EPI_PS_ADD) {
                 const int row = 2 * mt + (PREC == 1 ? sidx : 0);             // rows below the lane's base row
                 const int chadd = nt * 32 + (PREC == 1 ? 0 : 16 * sidx);     // channels (= floats in both layouts) above l_ch
@@ -672,7 +779,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
             e[0] = e[1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (!(has_skip && t.live)) return;
             if constexpr (PREC == 1) {                                       // split16 skip tensor, same layout as y
-                const float *ep = p.extra + (int64_t)f * p.extra_fs + t.opix * p.extra_ps + coff16(t.c8);
+                const float *ep = t.esrc ? t.esrc : p.extra + (int64_t)f * p.extra_fs + t.opix * p.extra_ps + coff16(t.c8);
                 e[0] = *reinterpret_cast<const f32x4 *>(ep);
                 e[1] = *reinterpret_cast<const f32x4 *>(ep + 8);
             } else {                                                         // fp32 skip tensor with generic strides
@@ -769,14 +876,24 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         }
     };
     using std::integral_constant;
-    auto with_act = [&](auto epi_c) {
-        if (p.act == BSVD_ACT_RELU6) finish(epi_c, integral_constant<int, BSVD_ACT_RELU6>{});
-        else if (p.act == BSVD_ACT_RELU) finish(epi_c, integral_constant<int, BSVD_ACT_RELU>{});
-        else finish(epi_c, integral_constant<int, BSVD_ACT_NONE>{});
+    auto with_act = [&](auto epi_c, auto psf_c) {
+        if (p.act == BSVD_ACT_RELU6) finish(epi_c, integral_constant<int, BSVD_ACT_RELU6>{}, psf_c);
+        else if (p.act == BSVD_ACT_RELU) finish(epi_c, integral_constant<int, BSVD_ACT_RELU>{}, psf_c);
+        else finish(epi_c, integral_constant<int, BSVD_ACT_NONE>{}, psf_c);
     };
-    if (p.epilogue == BSVD_EPI_PLAIN) with_act(integral_constant<int, BSVD_EPI_PLAIN>{});
-    else if (p.epilogue == BSVD_EPI_PS_ADD) with_act(integral_constant<int, BSVD_EPI_PS_ADD>{});
-    else with_act(integral_constant<int, BSVD_EPI_RESID>{});
+    using std::false_type;
+    using std::true_type;
+    if (p.epilogue == BSVD_EPI_PLAIN) with_act(integral_constant<int, BSVD_EPI_PLAIN>{}, false_type{});
+    else if (p.epilogue == BSVD_EPI_PS_ADD) {
+        if constexpr (PREC == 1) {
+            // UpBlock has no activation (bsvd_arch.py:263-267): the uniform-address form is instantiated for act 'none' only
+            if ((Cq & 31) == 0 && (p.extra == nullptr || p.extra_cs == 1) && p.act == BSVD_ACT_NONE)
+                finish(integral_constant<int, BSVD_EPI_PS_ADD>{}, integral_constant<int, BSVD_ACT_NONE>{}, true_type{});
+            else with_act(integral_constant<int, BSVD_EPI_PS_ADD>{}, false_type{});
+        } else {
+            with_act(integral_constant<int, BSVD_EPI_PS_ADD>{}, false_type{});
+        }
+    } else with_act(integral_constant<int, BSVD_EPI_RESID>{}, false_type{});
     TL(3);
 }
 

@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
 """HBM traffic per launch from rocprofv3 PMC passes (tools/pmc_run.sh): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
-FETCH_SIZE/WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
-reads, hence the factor 2 (/opt/skills/guides/MI355X_MICROARCH.md, HBM section).  WRITE_SIZE calibrates 1:1 on this
-workload: the conv kernels' measured 597 MB/launch equals their algorithmic output bytes exactly.
+FETCH_SIZE/WRITE_SIZE are reported in KiB.  The factor 2 on the read side is CALIBRATED on this kernel's own access pattern
+(tools/traffic_cal/, profiles/traffic_calibration.json): on gfx950 every memory-side read request is one 128-byte L2 line
+fill (TCC_EA0_RDREQ == TCC_MISS, TCC_EA0_RDREQ_32B == 0, TCC_BUBBLE == 0 for the patch-staging pattern and for a plain
+stream alike) and FETCH_SIZE tallies each at 64 B, so bytes = 2 x FETCH_SIZE for every pattern -- a plain stream reads back
+exactly 2.000.  What differs between patterns is how many LINES are fetched: the 16x16-pixel patch walk over 16-channel
+chunks fetches 1.08x the tensor (a 128-B line holds two chunks and is sometimes evicted between their passes), 1.11x with
+the 1-pixel halo (L2 absorbs most of the 26 % halo re-reads); a temporal-fusion layer additionally fetches the line with
+chunks 0/1 from BOTH neighbour frames for half a line of use each (+25 % of the input).  WRITE_SIZE calibrates 1:1 on this
+workload: the conv kernels' measured write bytes equal their algorithmic output bytes.
 usage: make_traffic.py <pmc dir> <out json>"""
 import collections, csv, glob, json, os, re, sys
 
 
 def kernel_key(name):
     """rocprof kernel name -> the variant names bench.py uses (LaunchTimer.variant)."""
-    m = re.search(r"conv3x3_kernel<bsvd::ConvCfg<(\d+), (\d+), (\d+), (\d+), (\d+), \d+(?:, (?:true|false))?>, (true|false), (\d)>", name)
+    m = re.search(r"conv3x3_kernel<bsvd::ConvCfg<(\d+), (\d+), (\d+), (\d+), (\d+), \d+(?:, (?:true|false))?>, (true|false), (\d)(?:, (true|false))?>", name)
     if m:
-        mt, nt, wm, wn, st, fast, prec = m.groups()
+        mt, nt, wm, wn, st, fast, prec, mix = m.groups()
         return "conv3x3_kernel<%s,%s,%s,%s,%s>%s%s" % (mt, nt, wm, wn, st, "[f16x3]" if prec == "1" else "[f32]",
-                                                      "" if fast == "true" else "[generic]")
+                                                      ("[fold8]" if mix == "true" else "") if fast == "true" else "[generic]")
     m = re.search(r"(head|tail)_kernel<(\d)>", name)
     if m:
         return m.group(0)          # bench.py appends the mode tag; match on the prefix
@@ -40,5 +46,7 @@ for k, v in agg.items():
     write = v["WRITE_SIZE"] / max(nw, 1) * 1024.0
     res[k] = {"launches_sampled": nf, "fetch_bytes_raw": fetch, "write_bytes": write, "hbm_bytes_per_launch": 2 * fetch + write}
 json.dump({"source": os.path.basename(d.rstrip("/")), "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch",
+           "calibration": "profiles/traffic_calibration.json: every memory-side read request is a 128-B line fill tallied at 64 B "
+                          "(stream 2.000; conv patch pattern: same factor, 1.08-1.11x the tensor in lines)",
            "kernels": res}, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
