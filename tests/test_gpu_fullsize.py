@@ -164,3 +164,34 @@ def test_auto_mode_falls_back_to_stream_when_the_clip_does_not_fit(monkeypatch):
     monkeypatch.setattr(torch.cuda, "memory_allocated", lambda *a, **k: 0)
     y2 = m(x[None])[0]
     assert m.last_mode == "stream" and torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_blind_c64_at_set8_geometry_vs_oracle_and_schedules(precision):
+    """BASELINE config 3 at its real geometry (Set8: 540x960, blind bsvd_c64 = 3-channel input, interm_ch 30 riding on two
+    zero padding channels, unbounded ReLU): 2 frames against the torch CPU oracle (WNet semantics), then 21 frames through
+    the clip schedule, the per-frame stream API and the chunked streaming_forward, bit for bit."""
+    import bsvd_amd
+    from oracle import bsvd_oracle as O
+    from seeded import seeded_clip
+    st = seeded_state(bsvd_keys([64, 128, 256], 64, 4, 3, 30, blind=True), 21)
+    m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, in_ch=4, out_ch=3, norm="none", act="relu", interm_ch=30, blind=True,
+                      pretrain_ckpt=None, precision=precision)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
+    m = m.to(_dev())
+    x = torch.from_numpy(seeded_clip((1, 2, 3, 540, 960), 22, kind="sigma30"))
+    want = O.bsvd_clip(x, O.to_torch_state(st), O.default_cfg(act="relu", interm_ch=30, blind=True))
+    got = m(x.to(_dev())).cpu()
+    err = float((got - want).abs().max())
+    print("blind c64 540x960 %s: max-abs vs CPU oracle %.2e (output magnitude %.1f)" % (precision, err, float(want.abs().max())))
+    assert err < 1e-3                                     # north_star budget; measured 3e-5 (fp32) / 1e-4 (f16x3)
+    xs = _sigma30_clip(21, 540, 960, 23)[:, :3].contiguous()
+    y = m.clip_forward(xs)
+    outs = [m.feedin_one_element(xs[i:i + 1]) for i in range(21)] + [m.feedin_one_element(None) for _ in range(16)]
+    m.feedin_one_element(None)
+    m.reset()
+    assert torch.equal(torch.cat(outs[16:]), y)
+    for chunk in (1, 4):
+        m.stream_chunk = chunk
+        assert torch.equal(m.streaming_forward(xs), y)
+    m.release_stream_buffers()
