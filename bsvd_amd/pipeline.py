@@ -117,3 +117,109 @@ class ClipPipeline:
                 yield self.pending.popleft().finish()
             self.submit(clip)
         yield from self.results()
+
+
+class LiveStream:
+    """One live feed through the per-frame streaming API (``BSVD.feedin_one_element``, bsvd_arch.py:485-488) with uint8 frames
+    on the host side: the streaming counterpart of ``ClipPipeline``.
+
+        feed(frame)  : uint8 [H,W,3] (RGB) -> enqueues upload (uint8 over PCIe), ``bsvd_u8_to_planar``, one pipeline step (a
+                       HIP-graph replay), ``bsvd_planar_to_u8`` and the download of whatever that step emitted on three HIP
+                       streams, then waits for the step fed ``depth-1`` calls earlier and returns the frame it emitted (None
+                       while the 16-step pipeline fills).
+        flush()      : feeds the 16 + 1 ``None`` steps of the reference's ``streaming_forward`` tail (:530-544), returns the
+                       remaining denoised frames in order and resets the stream.
+
+    Frame k comes back ``model.shift_num`` (16) feeds after it went in -- the network's own latency -- plus ``depth-1``
+    feeds of host pipelining (``depth=1``: every feed waits for its own step, lowest latency; ``depth>=2``: transfers of one
+    step overlap the compute of the next, highest rate).  Results keep submission order.  Not re-entrant (one stream per
+    instance, like the reference's module state)."""
+
+    def __init__(self, model, sigma=None, depth=2):
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.model, self.sigma, self.depth = model, sigma, depth
+        self.device = model._device()
+        if self.device.type != "cuda":
+            raise RuntimeError("LiveStream needs the model on a HIP device (model.cuda())")
+        with torch.cuda.device(self.device):
+            self.up, self.comp, self.down = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream())
+        self.slots, self.shape = None, None
+        self.inflight = collections.deque()          # (slot, has_output) in submission order
+        self.count = 0
+        model.reset()
+
+    def _alloc(self, shape):
+        self.shape = shape
+        self.slots = []
+        for _ in range(self.depth):                   # step k reuses the slot of step k - depth, which has been handed out
+            s = _Slot()
+            s.pin_in = torch.empty(shape, dtype=torch.uint8).pin_memory()
+            s.pin_out = torch.empty(shape, dtype=torch.uint8).pin_memory()
+            s.dev_in = torch.empty((1,) + shape, dtype=torch.uint8, device=self.device)
+            self.slots.append(s)
+
+    def _pop(self):
+        """oldest in-flight step -> its uint8 frame, or None if that step emitted nothing (pipeline fill)"""
+        slot, has_out = self.inflight.popleft()
+        slot.downloaded.synchronize()
+        return slot.pin_out.numpy().copy() if has_out else None
+
+    def _step(self, frame_u8):
+        slot = self.slots[self.count % len(self.slots)]
+        self.count += 1
+        with torch.cuda.device(self.device):
+            if frame_u8 is not None:
+                slot.pin_in.numpy()[...] = frame_u8
+                with torch.cuda.stream(self.up):
+                    slot.dev_in[0].copy_(slot.pin_in, non_blocking=True)
+                    slot.uploaded.record()
+            with torch.cuda.stream(self.comp):
+                x = None
+                if frame_u8 is not None:
+                    self.comp.wait_event(slot.uploaded)
+                    x = frames_to_input(slot.dev_in, self.sigma)
+                y = self.model.feedin_one_element(x)
+                if y is not None:
+                    slot.dev_out = output_to_frames(y.float())      # held by the slot until its download completed
+                slot.computed.record()
+            with torch.cuda.stream(self.down):
+                self.down.wait_event(slot.computed)
+                if y is not None:
+                    slot.pin_out.copy_(slot.dev_out[0], non_blocking=True)
+                slot.downloaded.record()
+        self.inflight.append((slot, y is not None))
+
+    def _drain(self, keep, outs):
+        while len(self.inflight) > keep:
+            r = self._pop()
+            if r is not None:
+                outs.append(r)
+
+    def feed(self, frame_u8):
+        frame_u8 = np.ascontiguousarray(frame_u8)
+        if frame_u8.dtype != np.uint8 or frame_u8.ndim != 3 or frame_u8.shape[-1] != 3:
+            raise ValueError("expected one uint8 frame [H,W,3]")
+        if frame_u8.shape[0] % 4 or frame_u8.shape[1] % 4:
+            raise ValueError("H and W must be multiples of 4 (pad first: denoise.pad_to_multiple_of_4)")
+        if self.shape != frame_u8.shape:
+            if self.inflight:
+                raise ValueError("frame size changed mid-stream; flush() first")
+            self._alloc(frame_u8.shape)
+        self._step(frame_u8)                          # step k is in flight ...
+        outs = []
+        self._drain(self.depth - 1, outs)             # ... while step k - (depth-1) is waited for and handed out
+        return outs[0] if outs else None
+
+    def flush(self):
+        """end of the feed: the 16 + 1 ``None`` steps of streaming_forward's tail, then everything in flight; returns the
+        remaining frames, oldest first, and resets the stream"""
+        outs = []
+        if self.slots is None:
+            return outs
+        for _ in range(self.model.shift_num + 1):
+            self._step(None)
+            self._drain(self.depth - 1, outs)
+        self._drain(0, outs)
+        self.model.reset()
+        return outs

@@ -148,3 +148,37 @@ def test_clip_pipeline_overlapped_transfers_match_the_direct_path(depth):
     assert all(np.array_equal(t.finish(), w) for t, w in zip(tickets, want[:4]))
     with pytest.raises(ValueError):
         pipe.submit(np.zeros((2, 30, 50, 3), np.uint8))     # not a multiple of 4
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_live_stream_uint8_frames_match_the_clip_path(depth):
+    """bsvd_amd.pipeline.LiveStream: uint8 frames in, one graph-replayed pipeline step per feed, uint8 frames out
+    shift_num + depth - 1 feeds later, byte-identical to the clip schedule on the same frames; reusable after flush()."""
+    import bsvd_amd
+    from bsvd_amd.frame_io import frames_to_input, output_to_frames
+    from bsvd_amd.pipeline import LiveStream
+    rs = np.random.RandomState(31)
+    dev = torch.device("cuda", 0)
+    st = seeded_state(bsvd_keys([64, 128, 256], 64, 4, 3, 64), 11)
+    m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, in_ch=4, out_ch=3, norm="none", act="relu6", interm_ch=64,
+                      pretrain_ckpt=None, precision="f16x3")
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
+    m = m.to(dev)
+    sigma = 30 / 255.0
+    live = LiveStream(m, sigma=sigma, depth=depth)
+    for T in (23, 5):
+        frames = rs.randint(0, 256, (T, 64, 96, 3)).astype(np.uint8)
+        want = output_to_frames(m.clip_forward(frames_to_input(torch.from_numpy(frames).to(dev), sigma))).cpu().numpy()
+        got, first = [], None
+        for k in range(T):
+            r = live.feed(frames[k])
+            if r is not None:
+                first = k if first is None else first
+                got.append(r)
+        if T > m.shift_num + depth - 1:
+            assert first == m.shift_num + depth - 1                 # network latency + host pipelining, nothing more
+        got += live.flush()
+        assert len(got) == T and all(g.dtype == np.uint8 for g in got)
+        assert np.array_equal(np.stack(got), want)
+    with pytest.raises(ValueError):
+        live.feed(np.zeros((30, 50, 3), np.uint8))
