@@ -141,9 +141,14 @@ class _HipNet(nn.Module):
         require_hip()
         sig = (self._signature(), str(device), self.precision)
         if self._packed is None or self._packed_sig != sig:
+            # the ring/graph engines of the stream schedule bake the packed-weight addresses into their launch plans: drop them
+            # BEFORE the old pack is freed (a new executor may even reuse the old one's id())
+            if getattr(self, "_stream_engs", None):
+                self.release_stream_buffers()
             self._packed = PackedNet(self.net, self._engine_state(), device, self.precision)
             self._packed_sig = sig
             self._exec = HipExecutor(self._packed)
+            self._exec_gen = getattr(self, "_exec_gen", 0) + 1
         return self._exec
 
     def _device(self):
@@ -275,7 +280,7 @@ class BSVD(_HipNet):
         pin, pout = planar_ok(ex, self.net)
         if not (pin and pout and self.stream_rings):
             return None
-        key = (id(ex), tuple(frame_shape), None if self.clamp is None else tuple(self.clamp), self.stream_graphs)
+        key = (self._exec_gen, tuple(frame_shape), None if self.clamp is None else tuple(self.clamp), self.stream_graphs)
         if self._stream_key != key:
             if len(frame_shape) != 3 or frame_shape[0] != self.net.net_in_ch:
                 raise ValueError("expected frames [%d,H,W], got %s" % (self.net.net_in_ch, tuple(frame_shape)))

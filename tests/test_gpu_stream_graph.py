@@ -86,3 +86,23 @@ def test_1080p_stream_reaches_steady_state_and_equals_clip():
         m.stream_chunk = chunk
         assert torch.equal(m.streaming_forward(x), want)
     m.release_stream_buffers()
+
+
+def test_weight_update_rebuilds_rings_and_graphs():
+    """The step plans bake packed-weight addresses into HIP graphs: an in-place parameter update must drop them together
+    with the old pack (never replay a graph over freed weights)."""
+    m = _model("f16x3")
+    x = torch.rand(19, 4, 32, 48, device="cuda:0")
+    for _ in range(3):
+        y0 = _per_frame(m, x)
+    assert torch.equal(y0, m.clip_forward(x)) and m._stream_eng.stats["graph_replays"] > 0
+    old = m._stream_eng
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.01)
+    want = m.clip_forward(x)                       # re-packs; the old engines are released with the old pack
+    assert m._stream_eng is None and not old.rings
+    assert not torch.equal(want, y0)
+    for _ in range(3):
+        assert torch.equal(_per_frame(m, x), want)
+        assert torch.equal(m.streaming_forward(x), want)
