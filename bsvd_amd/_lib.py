@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BSVD_HIP_LIB") or os.path.join(_HERE, "libbsvd_hip.so")   # env override: A/B tuning builds
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 BSVD_F32, BSVD_F16, BSVD_F16X3 = 0, 1, 2
 ACT = {"none": 0, "relu": 1, "relu6": 2}
 EPI_PLAIN, EPI_PS_ADD, EPI_RESID = 0, 1, 2
@@ -46,6 +46,7 @@ class BsvdConvArgs(ctypes.Structure):
         ("x_planar_ch", ctypes.c_int32), ("y_planar_ch", ctypes.c_int32), ("y_clamp", ctypes.c_int32),
         ("y_lo", ctypes.c_float), ("y_hi", ctypes.c_float),
         ("extra_split", ctypes.c_int32),
+        ("tile_order", ctypes.c_int32),
     ]
 
 

@@ -266,6 +266,7 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
         vec = vec && (a->halo_next_pstride & 3) == 0 && (a->halo_next_coff & 3) == 0 && (((uintptr_t)a->halo_next) & 15) == 0;
     p.vec_ok = vec ? 1 : 0;
     p.ablate = 0;
+    p.flip = a->tile_order ? 1 : 0;
     p.prec = a->dtype == BSVD_F16X3 ? 1 : 0;
     p.extra_split = a->extra_split;
     p.y_planar_ch = a->y_planar_ch; p.y_clamp = a->y_clamp; p.y_lo = a->y_lo; p.y_hi = a->y_hi;

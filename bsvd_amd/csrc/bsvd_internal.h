@@ -24,6 +24,7 @@ struct ConvParams {
     int32_t ntx, nty, nct;   // tiles in x, y and output-channel tiles
     int32_t vec_ok;          // 1: every 4-channel group of the gather comes from one source, 16-B aligned
     int32_t ablate;          // only read by -DBSVD_ABLATE timing builds (tools/), always 0 in the product
+    int32_t flip;            // 1: walk the tiles in reverse order (BsvdConvArgs.tile_order; see launch_cfg)
     int32_t prec;            // 0 = exact fp32, 1 = split16 (BSVD_F16X3)
     int32_t extra_split;     // planar-output layer in split mode: the residual base is a split16 NHWC tensor
     int32_t y_planar_ch;     // > 0: y is planar [frames][y_planar_ch][H][W] fp32 (split mode: written by the MFMA kernel)

@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q8 = nblk >> 3, r8 = nblk & 7;
     int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    if (p.flip) lid = nblk - 1 - lid;     // reverse walk: start with the tiles the producer wrote last (still in the Infinity Cache)
     const int ct = lid % p.nct; lid /= p.nct;
     const int tx = lid % p.ntx; lid /= p.ntx;
     const int ty = lid % p.nty;

@@ -33,6 +33,7 @@ class PackedNet:
         self.device = device
         self.precision = precision
         self.tensors = {}
+        self.order = {sp.key: i for i, sp in enumerate(net.layers)}      # position in the layer-major walk (tile_order parity)
         edge = set()
         if precision == "f16x3":
             # the entry layer (planar 3/4-channel input) runs on the fp32 VALU kernel and keeps an fp32 pack; every other
@@ -224,4 +225,6 @@ class HipExecutor:
         a.Cin, a.Cout = sp.cin_pad, sp.cout_pad
         a.stride = sp.stride
         a.act, a.epilogue, a.dtype = _lib.ACT[sp.act], sp.epilogue, self.dtype
+        # consecutive layers walk their tiles in opposite directions: each starts where its producer finished (Infinity Cache)
+        a.tile_order = self.packed.order.get(sp.key, 0) & 1
         return a, y
