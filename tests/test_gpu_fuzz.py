@@ -75,3 +75,31 @@ def test_random_clip_whole_network(seed):
         assert err < 1e-3
         m.engine_mode = "stream"
         assert torch.equal(m(x.to(dev)), y)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_streams_on_rings_and_graphs(seed):
+    """Random clip lengths (1..45 frames, i.e. from 'never reaches the steady state' to several ring periods), frame sizes,
+    chunk sizes and lag on/off through the ring/graph engine, three clips back to back on one model (plans of one clip are
+    graphs for the next): always bit-identical to the clip schedule; per-frame API and the c32-sized network included."""
+    import torch
+    import bsvd_amd
+    rs = np.random.RandomState(5000 + seed)
+    chns, mid = ([64, 128, 256], 64) if seed % 3 else ([32, 64, 128], 32)
+    torch.manual_seed(seed)
+    m = bsvd_amd.BSVD(chns=chns, mid_ch=mid, norm="none", act="relu6", interm_ch=chns[0], pretrain_ckpt=None,
+                      precision="f16x3" if seed % 2 else "fp32").to("cuda:0").eval()
+    H, W = 4 * int(rs.randint(2, 10)), 4 * int(rs.randint(2, 10))
+    for clip in range(3):
+        T = int(rs.randint(1, 46))
+        x = torch.rand(T, 4, H, W, device="cuda:0")
+        want = m.clip_forward(x)
+        m.stream_chunk = [1, 2, 3, 5, 8, "auto"][int(rs.randint(0, 6))]
+        m.stream_overlap = bool(rs.randint(0, 2))
+        for rep in range(2):
+            assert torch.equal(m.streaming_forward(x), want), (seed, clip, T, H, W, m.stream_chunk, m.stream_overlap)
+        outs = [m.feedin_one_element(x[i:i + 1]) for i in range(T)] + [m.feedin_one_element(None) for _ in range(m.shift_num)]
+        assert m.feedin_one_element(None) is None
+        m.reset()
+        assert torch.equal(torch.cat([o for o in outs if o is not None]), want)
+    m.release_stream_buffers()

@@ -138,3 +138,21 @@ def test_chunked_steps_equal_the_frame_by_frame_pipeline_bitwise(chunk):
     assert maxabs(_run_lagged(eng, x[:5], net.shift_num), _run_pipeline(net, st, x[:5])) < 2e-5
     from bsvd_amd.stream_plan import ring_bytes_estimate
     assert ring_bytes_estimate(net, 8, 12, chunk) == eng.ring_bytes
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_lengths_chunks_and_lag_on_cpu(seed):
+    """Seeded sweep of (clip length, chunk, entry point) over the ring engine with NaN-poisoned rings: the host logic alone
+    (no GPU) must reproduce the allocating pipeline for every combination, also for clips shorter than the pipeline depth."""
+    rs = np.random.RandomState(700 + seed)
+    net = make_netspec([16, 32, 64], 16, 4, 3, "relu6", 16)
+    st = seeded_state(bsvd_keys([16, 32, 64], 16, 4, 3, 16), 5)
+    chunk = int(rs.randint(1, 7))
+    eng, _ = _engine(net, st, 8, 8, 4, chunk=chunk)
+    for clip in range(3):
+        T = int(rs.randint(1, 30))
+        x = torch.from_numpy(seeded_clip((1, T, 4, 8, 8), 900 + 10 * seed + clip, kind="sigma30"))[0]
+        want = _run_pipeline(net, st, x)
+        run = _run_lagged if rs.randint(0, 2) else _run_feed
+        got = run(eng, x, net.shift_num)
+        assert got.shape == want.shape and maxabs(got, want) < 2e-5, (seed, clip, T, chunk, run.__name__)
