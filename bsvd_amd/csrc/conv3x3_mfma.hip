@@ -205,11 +205,21 @@ struct ChunkSrc {          // wave-uniform description of one 16-channel chunk's
 #define BSVD_TUNE_S2_GROUP 1       // slices per round trip of the split-fp16 stride-2 patch refill
 #endif
 #ifndef BSVD_TUNE_S2_PAIR
-#define BSVD_TUNE_S2_PAIR 0        // 1: split-fp16 stride-2 tile fetches BOTH 16-channel chunks of a 128-byte line in one go (odd chunk held in
-                                   // registers, one round trip per two chunks).  Measured r02: bit-identical, but the 36 extra VGPRs cost the third
-                                   // wave per SIMD and the kernel gets SLOWER (2.61 vs 2.41 ms per clip): occupancy, not the re-fetched lines, is
-                                   // what this tile lives on (the re-fetches are largely served by the 256 MiB Infinity Cache, which the EA counters
-                                   // cannot tell from HBM)
+#define BSVD_TUNE_S2_PAIR 2        // refill of the split-fp16 stride-2 tile's single LDS patch buffer (r02 measurements, ms per 10-frame clip for the
+                                   // four stride-2 launches; all variants bit-identical):
+                                   //   0: at every chunk boundary load -> store, row slices or flattened items (BSVD_TUNE_S2_FLAT): 2.36-2.46
+                                   //   1: both 16-channel chunks of a 128-byte line fetched at once, the odd one held in registers: 2.61
+                                   //   2: REGISTER DOUBLE BUFFER -- chunk cb+1 is requested at the boundary before chunk cb and waits in 36 VGPRs
+                                   //      (flattened items: all 256 lanes carry a piece); a boundary is barrier + ds_write + barrier: 2.29 (default)
+                                   //   3: 1 + 2 (line pairs requested one chunk period ahead, 72 VGPRs): 2.49
+                                   // 1 and 3 halve the memory-side line fetches (2.04x -> ~1.1x of the input) and are SLOWER: the re-fetched lines come
+                                   // from the Infinity Cache, the tile lives on occupancy and on not waiting at its boundaries
+#endif
+#ifndef BSVD_TUNE_S2_PAIR_OCC
+#define BSVD_TUNE_S2_PAIR_OCC 2    // waves/SIMD the register-holding variants (BSVD_TUNE_S2_PAIR 1|2) are compiled for
+#endif
+#ifndef BSVD_TUNE_S2_FLAT
+#define BSVD_TUNE_S2_FLAT 9        // split-fp16 stride-2 tile: 16-byte items per lane and round trip of the flattened refill / prologue fill (9 = whole patch; 0: row slices)
 #endif
 #ifndef BSVD_TUNE_FILL
 #define BSVD_TUNE_FILL 1           // 1: the whole LDS patch of a prologue / single-buffer refill in flight at once
@@ -220,7 +230,7 @@ constexpr int occ_of()
     // exact-fp32 stride 2 (single patch buffer): the refill holds the whole 17x33 patch in registers (72 VGPRs) -> 2 waves/SIMD
     if (C::STRIDE == 2 && PREC == 0 && C::OCC > BSVD_TUNE_S2F32_OCC) return BSVD_TUNE_S2F32_OCC;
     // split-fp16 single-buffer tile with the odd chunk of every 128-byte line held in registers (72 VGPRs): 2 waves/SIMD
-    if (!C::DBUF && PREC == 1 && BSVD_TUNE_S2_PAIR && C::OCC > 2) return 2;
+    if (!C::DBUF && PREC == 1 && BSVD_TUNE_S2_PAIR && C::OCC > BSVD_TUNE_S2_PAIR_OCC) return BSVD_TUNE_S2_PAIR_OCC;
     return C::OCC;
 }
 
@@ -450,11 +460,16 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         // side and the 64->128 layer running at 5.1 TB/s, i.e. HBM-bound on re-fetches.  So every even boundary requests both
         // halves of each line back to back -- the even chunk goes to LDS, the odd one waits in registers (hold, 72 VGPRs) and
         // is published at the next boundary without touching memory.
-        constexpr bool PAIR = !C::DBUF && PREC == 1 && BSVD_TUNE_S2_PAIR;
+        constexpr bool PAIR = !C::DBUF && PREC == 1 && BSVD_TUNE_S2_PAIR == 1;
+        constexpr bool REGPF = !C::DBUF && PREC == 1 && BSVD_TUNE_S2_PAIR == 2;     // register double buffer: chunk cb+1 in flight during chunk cb
+        // PAIRPF (3): both of the above -- the two chunks of a 128-byte line are requested together, one chunk period before the
+        // first is needed, and wait in registers (2 x 36 VGPRs): every line is fetched once AND no boundary waits for memory
+        constexpr bool PAIRPF = !C::DBUF && PREC == 1 && BSVD_TUNE_S2_PAIR == 3;
         // PAIR items: the patch flattened to (row, column, 16-byte quad) items, 256 per pass -- the row-slice map above keeps
         // only 132 of 256 lanes busy on the 33-pixel rows of this tile, which would double the registers the held chunk costs
         constexpr int PNITEM = C::PH * C::ROW_ITEMS, PNI = (PNITEM + 255) / 256;
-        [[maybe_unused]] f32x4 hold[PAIR ? PNI : 1];
+        [[maybe_unused]] f32x4 hold[(PAIR || REGPF || PAIRPF) ? PNI : 1];
+        [[maybe_unused]] f32x4 hold_even[PAIRPF ? PNI : 1];
         auto pair_item = [&](int i, unsigned &voff, int &lds_off, bool &in_patch) {
             const int e = tid + 256 * i;
             const int prow = e / C::ROW_ITEMS, rem = e - prow * C::ROW_ITEMS;
@@ -488,11 +503,70 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
             for (int i = 0; i < PNI; ++i) {
                 unsigned voff; int lo; bool inp;
                 pair_item(i, voff, lo, inp);
-                if constexpr (PAIR) if (inp) *reinterpret_cast<f32x4 *>(pb + lo) = hold[i];
+                if constexpr (PAIR || REGPF || PAIRPF) if (inp) *reinterpret_cast<f32x4 *>(pb + lo) = hold[i];
             }
         };
-        if constexpr (PAIR) fill_pair(0, patch_buf);
+        // Single-buffer refill on the flattened item map (FLAT): all 256 lanes carry a 16-byte piece per load instruction (the
+        // row-slice map keeps 132 of 256 busy on this tile's 33-pixel rows), so the same registers cover the patch in half the
+        // round trips: BSVD_TUNE_S2_FLAT items per lane and round trip (9 items = the whole 17x33 patch).
+        auto publish_even = [&](float *pb) {
+#pragma unroll
+            for (int i = 0; i < PNI; ++i) {
+                unsigned voff; int lo; bool inp;
+                pair_item(i, voff, lo, inp);
+                if constexpr (PAIRPF) if (inp) *reinterpret_cast<f32x4 *>(pb + lo) = hold_even[i];
+            }
+        };
+        auto prefetch_pair = [&](int cbe) {            // PAIRPF: chunks cbe (even) and cbe+1 of every line, back to back
+            const __amdgpu_buffer_rsrc_t re = cbe < ncb ? rs_cur : make_rsrc(s.cur, 0u);
+            const __amdgpu_buffer_rsrc_t ro = cbe + 1 < ncb ? rs_cur : make_rsrc(s.cur, 0u);
+#pragma unroll
+            for (int i = 0; i < PNI; ++i) {
+                unsigned voff; int lo; bool inp;
+                pair_item(i, voff, lo, inp);
+                if constexpr (PAIRPF) {
+                    hold_even[i] = buf_load4(re, voff, (unsigned)cbe * 64u);
+                    hold[i] = buf_load4(ro, voff, (unsigned)cbe * 64u + 64u);
+                }
+            }
+        };
+        constexpr bool FLAT = !C::DBUF && PREC == 1 && !PAIR && !PAIRPF && (REGPF || BSVD_TUNE_S2_FLAT > 0);
+        auto prefetch_hold = [&](int cbn) {            // REGPF: request chunk cbn into registers; it is published at the next boundary
+#pragma unroll
+            for (int i = 0; i < PNI; ++i) {
+                unsigned voff; int lo; bool inp;
+                pair_item(i, voff, lo, inp);
+                if constexpr (REGPF) hold[i] = buf_load4(cbn < ncb ? rs_cur : make_rsrc(s.cur, 0u), voff, (unsigned)cbn * 64u);
+            }
+        };
+        auto fill_flat = [&](const ChunkSrc &c, float *pb) {
+            constexpr int GI = BSVD_TUNE_S2_FLAT > 0 ? BSVD_TUNE_S2_FLAT : 1;
+#pragma unroll
+            for (int g0 = 0; g0 < PNI; g0 += GI) {
+                f32x4 v[GI];
+#pragma unroll
+                for (int j = 0; j < GI; ++j)
+                    if (g0 + j < PNI) {
+                        const int e = tid + 256 * (g0 + j);
+                        const int prow = e / C::ROW_ITEMS, rem2 = e - prow * C::ROW_ITEMS;
+                        const int gy = iy0 + prow, gxx = ix0 + (rem2 >> 2);
+                        const bool ok = e < PNITEM && gy >= 0 && gy < p.H && gxx >= 0 && gxx < p.W;
+                        v[j] = buf_load4(c.rs, ok ? (unsigned)(gy * p.W + gxx) * c.ps4 + (rem2 & 3) * 16u : BSVD_OOB, c.soff);
+                    }
+#pragma unroll
+                for (int j = 0; j < GI; ++j)
+                    if (g0 + j < PNI) {
+                        const int e = tid + 256 * (g0 + j);
+                        const int prow = e / C::ROW_ITEMS, rem2 = e - prow * C::ROW_ITEMS;
+                        if (e < PNITEM) *reinterpret_cast<f32x4 *>(pb + prow * C::ROWP + (rem2 >> 2) * C::PS + (rem2 & 3) * 4) = v[j];
+                    }
+            }
+        };
+        if constexpr (PAIRPF) { prefetch_pair(0); publish_even(patch_buf); }
+        else if constexpr (PAIR) fill_pair(0, patch_buf);
+        else if constexpr (FLAT) fill_flat(chunk_src(0), patch_buf);
         else fill_patch(chunk_src(0), patch_buf);
+        if constexpr (REGPF) prefetch_hold(1);
         __syncthreads();
         TL(1);
 
@@ -553,12 +627,24 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
             __syncthreads();   // one barrier per 16-channel chunk (9 taps, 288 MFMAs per wave)
             if constexpr (!C::DBUF) {
                 if (cb + 1 < ncb) {        // single buffer: everybody is done reading it -> refill, publish
-                    if constexpr (PAIR) {
+                    if constexpr (PAIRPF) {
+                        if ((cb + 1) & 1) {
+                            publish_hold(patch_buf);          // the odd chunk that came with chunk cb
+                            prefetch_pair(cb + 2);            // next line pair: one chunk period ahead of its first use
+                        } else {
+                            publish_even(patch_buf);
+                        }
+                    } else if constexpr (REGPF) {
+                        publish_hold(patch_buf);
+                        prefetch_hold(cb + 2);
+                    } else if constexpr (PAIR) {
                         if ((cb + 1) & 1) {
                             publish_hold(patch_buf);
                         } else {
                             fill_pair(cb + 1, patch_buf);
                         }
+                    } else if constexpr (FLAT) {
+                        fill_flat(cn, patch_buf);
                     } else {
                         fill_patch(cn, patch_buf);
                     }
