@@ -312,6 +312,28 @@ class BSVD(_HipNet):
                 return n
         return 1
 
+    def prepare_stream(self, H, W, all_flush_phases=False, dtype=torch.float32):
+        """Optional warm-up before going live: drives dummy streams of HxW frames through ``feedin_one_element`` until every
+        launch plan of the pipeline fill and of the steady state is a captured HIP graph, so that the first real frames pay
+        neither the one-time batched launches nor the ~1 ms graph captures (a stream captures a plan at its second
+        sighting).  ``all_flush_phases`` also captures the 17-step flush for every stream length modulo the ring period
+        (10 dummy streams instead of one).  Returns the per-frame engine's statistics."""
+        from .stream_plan import RING_PERIOD
+        dev = self._device()
+        frame = torch.zeros((1, self.net.net_in_ch, H, W), dtype=dtype, device=dev)
+        base = 2 * self.shift_num + RING_PERIOD            # fill, then one full ring period of steady-state steps
+        lengths = [base + i for i in range(RING_PERIOD)] if all_flush_phases else [base]
+        for n in lengths:
+            for _ in range(2):                             # first pass: plans are issued directly; second: captured
+                self.reset()
+                for _ in range(n):
+                    self.feedin_one_element(frame)
+                for _ in range(self.shift_num + 1):
+                    self.feedin_one_element(None)
+        self.reset()
+        eng = self._stream_eng
+        return None if eng is None else dict(eng.stats, graphs=sum(1 for g in eng.graphs.values() if g[0]), plans=len(eng.plans))
+
     def feedin_one_element(self, x):
         """x: [1,C,H,W] tensor or None (flush).  Returns the frame fed ``shift_num`` steps earlier, or None.
         Runs on preallocated rings; a step whose launch pattern has been seen before is one HIP-graph replay."""

@@ -106,3 +106,16 @@ def test_weight_update_rebuilds_rings_and_graphs():
     for _ in range(3):
         assert torch.equal(_per_frame(m, x), want)
         assert torch.equal(m.streaming_forward(x), want)
+
+
+def test_prepare_stream_leaves_nothing_to_capture_for_the_live_feed():
+    m = _model("f16x3")
+    st = m.prepare_stream(32, 48, all_flush_phases=True)
+    assert st["graphs"] > 16 + 10 and st["graph_captures"] == st["graphs"]
+    before = dict(m._stream_eng.stats)
+    x = torch.rand(47, 4, 32, 48, device="cuda:0")       # any length: fill, steady state and flush are all graphs already
+    want = m.clip_forward(x)
+    assert torch.equal(_per_frame(m, x), want)
+    after = m._stream_eng.stats
+    assert after["graph_captures"] == before["graph_captures"] and after["batch_launches"] == before["batch_launches"]
+    assert after["graph_replays"] - before["graph_replays"] == 47 + 16      # the 17th flush feed finds the pipeline empty: no launch
