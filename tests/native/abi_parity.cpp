@@ -216,11 +216,57 @@ static void case_batch_and_graph() {
     ABI_OK(bsvd_graph_destroy(g)); HIP_OK(hipStreamDestroy(cap)); HIP_OK(hipStreamDestroy(run));
 }
 
+// BiBufferConv (bsvd_arch.py:53-114) as a torch-free host would stream it: the two frame buffers of the reference become a ring
+// of three device frames (next / pending / past), every step is one bsvd_conv3x3 on fixed addresses, and the three ring phases
+// of the steady state are three HIP graphs captured once and replayed -- compared bit for bit with ONE clip launch over the
+// same frames (the kernel reads t-1 / t+1 inside the clip).  Stream start / end (no past / no next frame: the zeros of :94,104)
+// are NULL halos, launched directly.
+static void case_stream_ring_graphs() {
+    const int T = 11, C = 128, H = 12, W = 20, fold = C / 8;
+    const size_t fr = (size_t)H * W * C;
+    auto x = randv((size_t)T * C * H * W, 1.f), w = randv((size_t)C * C * 9, 0.04f), b = randv(C, 0.1f);
+    float *dx = dev(to_nhwc(x, T, C, H, W, C)), *dclip = dev_zeros(T * fr), *dstream = dev_zeros(T * fr);
+    Packed pk = pack(w, b, C, C, C, C, 0, BSVD_F32);
+    BsvdConvArgs a; memset(&a, 0, sizeof(a));
+    a.x_frame_stride = (int64_t)fr; a.fold = fold; a.w_packed = pk.w; a.bias_packed = pk.b; a.y_frame_stride = (int64_t)fr;
+    a.H = H; a.W = W; a.Cin = C; a.Cout = C; a.stride = 1; a.act = BSVD_ACT_RELU6; a.epilogue = BSVD_EPI_PLAIN; a.dtype = BSVD_F32;
+    BsvdConvArgs clip = a; clip.x = dx; clip.y = dclip; clip.frames = T;
+    ABI_OK(bsvd_conv3x3(&clip, nullptr)); HIP_OK(hipDeviceSynchronize());
+    float *ring[3], *oring[3];
+    for (int i = 0; i < 3; ++i) { ring[i] = dev_zeros(fr); oring[i] = dev_zeros(fr); }
+    hipStream_t cap, run; HIP_OK(hipStreamCreate(&cap)); HIP_OK(hipStreamCreate(&run));
+    void *graph[3] = {nullptr, nullptr, nullptr};
+    int replays = 0, direct = 0;
+    for (int s = 0; s <= T; ++s) {                       // step s: frame s arrives (s < T), frame s-1 leaves
+        if (s < T) HIP_OK(hipMemcpyAsync(ring[s % 3], dx + s * fr, fr * 4, hipMemcpyDeviceToDevice, run));
+        if (s == 0) continue;                            // first call of BiBufferConv returns None (:86-100)
+        const int t = s - 1;
+        BsvdConvArgs st = a; st.frames = 1; st.x = ring[t % 3]; st.y = oring[t % 3];
+        if (t > 0) { st.halo_prev = ring[(t - 1) % 3]; st.halo_prev_pstride = C; st.halo_prev_coff = fold; }
+        if (s < T) { st.halo_next = ring[s % 3]; st.halo_next_pstride = C; st.halo_next_coff = 0; }
+        if (t > 0 && s < T) {                            // steady state: all three ring slots in play, addresses repeat with period 3
+            const int ph = s % 3;
+            if (!graph[ph]) {
+                int32_t nodes = 0;
+                ABI_OK(bsvd_graph_begin(cap)); ABI_OK(bsvd_conv3x3_batch(&st, 1, cap)); ABI_OK(bsvd_graph_end(cap, &graph[ph], &nodes));
+            } else ++replays;
+            ABI_OK(bsvd_graph_launch(graph[ph], run));
+        } else { ABI_OK(bsvd_conv3x3(&st, run)); ++direct; }
+        HIP_OK(hipMemcpyAsync(dstream + t * fr, oring[t % 3], fr * 4, hipMemcpyDeviceToDevice, run));
+    }
+    HIP_OK(hipStreamSynchronize(run));
+    report("BiBufferConv streamed on a 3-frame ring with per-phase HIP graphs == one clip launch (bitwise)",
+           maxabs(host(dstream, T * fr), host(dclip, T * fr)), 1e-30);
+    if (replays != T - 2 - 3 || direct != 2) { printf("stream bookkeeping: %d replays, %d direct launches\n", replays, direct); ++failures; }
+    for (auto g : graph) ABI_OK(bsvd_graph_destroy(g));
+    HIP_OK(hipStreamDestroy(cap)); HIP_OK(hipStreamDestroy(run));
+}
+
 int main() {
     if (bsvd_abi_version() != BSVD_ABI_VERSION || bsvd_conv_args_size() != (int)sizeof(BsvdConvArgs)) { printf("ABI mismatch\n"); return 1; }
     int n = 0; HIP_OK(hipGetDeviceCount(&n)); if (n < 1) { printf("no HIP device\n"); return 1; }
     HIP_OK(hipSetDevice(0));
-    case_tsm(); case_stride2(); case_pixel_shuffle(); case_split_chain(); case_batch_and_graph();
+    case_tsm(); case_stride2(); case_pixel_shuffle(); case_split_chain(); case_batch_and_graph(); case_stream_ring_graphs();
     printf(failures ? "abi_parity: %d FAILED\n" : "abi_parity: all cases ok\n", failures);
     return failures ? 1 : 0;
 }
