@@ -53,8 +53,22 @@
 #ifndef BSVD_TUNE_FAT_OCC
 #define BSVD_TUNE_FAT_OCC 2        // waves/SIMD the 128-accumulator tiles are compiled for
 #endif
+#ifndef BSVD_TUNE_APF
+#define BSVD_TUNE_APF 1        // split DBUF tiles that request the NEXT tap's pixel fragments in the middle of the current tap: 0 none, 1 the exit tile (NT == 1), 2 all, 3 fat tiles
+#endif
 #ifndef BSVD_TUNE_D
 #define BSVD_TUNE_D 1          // patch slices stored D (1|2) taps after their load was issued
+#endif
+
+// patch-slice register ring of the K loop: loaded into slot tap%3, stored BSVD_TUNE_D taps later
+#if BSVD_TUNE_D == 2
+#define S_OLD0 s1
+#define S_OLD1 s2
+#define S_OLD2 s0
+#else
+#define S_OLD0 s2
+#define S_OLD1 s0
+#define S_OLD2 s1
 #endif
 
 namespace bsvd {
@@ -572,6 +586,75 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
 
         const int nsteps = ncb * 9;
         int step = 0;
+        // APF (A-operand prefetch): the plain loop below gives every tap one load phase (8 ds_read_b128 of the pixel fragments +
+        // the weight / slice requests) and then its 24 MFMAs; a wave's LDS latency is covered only while the OTHER wave of the
+        // SIMD happens to be in its MFMA phase (timeline: the K loop runs at 63 % of the two-wave MFMA issue rate).  Here the
+        // pixel fragments of tap k+1 are requested in the middle of tap k: the `lo` halves are dead after the first of the three
+        // passes (their registers take the next tap's `lo`), the `hi` halves are double-buffered (+16 VGPRs), so a wave enters a
+        // tap with its operands already in registers.  Same MFMAs in the same order on the same accumulators: bit-identical.
+        // Measured r02 (interleaved A/B, ms per clip): fat 128-accumulator tile 20.05 -> 20.31 (SLOWER: its two waves per SIMD already
+        // alternate load and MFMA phases, and the scheduling fences cost more than the exposed latency), 64-channel tile 6.33 =,
+        // the 32-channel exit tile 0.63 -> 0.58.  Default: the exit tile only.
+        constexpr bool APF = PREC == 1 && C::DBUF && C::RING == 3 &&
+                             (BSVD_TUNE_APF == 2 || (BSVD_TUNE_APF == 1 && C::NT == 1) || (BSVD_TUNE_APF == 3 && C::MT * C::NT >= 8));
+        if constexpr (APF) {
+            auto load_hi = [&](const float *pc, int tap_off, f32x4 (&h)[C::MT]) {
+#pragma unroll
+                for (int mt = 0; mt < C::MT; ++mt) h[mt] = *reinterpret_cast<const f32x4 *>(pc + a_lane + tap_off + (2 * mt * C::STRIDE) * C::ROWP);
+            };
+            auto load_lo = [&](const float *pc, int tap_off, f32x4 (&l)[C::MT]) {
+#pragma unroll
+                for (int mt = 0; mt < C::MT; ++mt) l[mt] = *reinterpret_cast<const f32x4 *>(pc + a_lane + tap_off + (2 * mt * C::STRIDE) * C::ROWP + 8);
+            };
+            auto pass = [&](const f32x4 (&av)[C::MT], const f32x4 (&bv)[C::NT][2], int bpart) {
+#pragma unroll
+                for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < C::NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bv[nt][bpart]),
+                                                                             __builtin_bit_cast(f16x8, av[mt]), acc[mt][nt], 0, 0, 0);
+            };
+            for (int cb = 0; cb < ncb; ++cb) {
+                const float *pcur = patch_buf + (cb & 1) * C::PATCH_FLOATS;
+                float *pnext = patch_buf + ((cb + 1) & 1) * C::PATCH_FLOATS;
+                ChunkSrc cn = chunk_src(cb + 1 < ncb ? cb + 1 : cb);
+                if (cb + 1 >= ncb) cn.rs = make_rsrc(s.cur, 0u);
+                f32x4 s0[C::P], s1[C::P], s2[C::P];
+#pragma unroll
+                for (int i = 0; i < C::P; ++i) s1[i] = s2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 hiA[C::MT], hiB[C::MT], loA[C::MT], loB[C::MT];
+                load_hi(pcur, 0, hiA);
+                load_lo(pcur, 0, loA);
+#define BSVD_APF_TAP(T, HC, LC, HN, LN, BCUR, BFILL, SNEW, SOLD)                                                           \
+                {                                                                                                        \
+                    load_b(step + 2 < nsteps ? step + 2 : nsteps - 1, BFILL);                                            \
+                    slice_load(cn, (T) * C::ROWS_PER_SLICE, SNEW);                          /* rows >= PH: zeros */       \
+                    __builtin_amdgcn_sched_barrier(0);                                                                   \
+                    pass(LC, BCUR, 0);                                                      /* hi(w) x lo(x) */           \
+                    __builtin_amdgcn_sched_barrier(0);                                                                   \
+                    if constexpr ((T) < 8) {                                                                             \
+                        load_lo(pcur, (((T) + 1) / 3) * C::ROWP + (((T) + 1) % 3) * C::PS, LN);                          \
+                        load_hi(pcur, (((T) + 1) / 3) * C::ROWP + (((T) + 1) % 3) * C::PS, HN);                          \
+                    }                                                                                                    \
+                    __builtin_amdgcn_sched_barrier(0);                                      /* reads stay HERE: 16 MFMAs of cover */ \
+                    pass(HC, BCUR, 1);                                                      /* lo(w) x hi(x) */           \
+                    pass(HC, BCUR, 0);                                                      /* hi(w) x hi(x) */           \
+                    if ((T) >= BSVD_TUNE_D && (T) <= C::NSLICE - 1 + BSVD_TUNE_D) slice_store(pnext, ((T) - BSVD_TUNE_D) * C::ROWS_PER_SLICE, SOLD); \
+                    ++step;                                                                                              \
+                }
+                BSVD_APF_TAP(0, hiA, loA, hiB, loB, b0, b2, s0, S_OLD0)
+                BSVD_APF_TAP(1, hiB, loB, hiA, loA, b1, b0, s1, S_OLD1)
+                BSVD_APF_TAP(2, hiA, loA, hiB, loB, b2, b1, s2, S_OLD2)
+                BSVD_APF_TAP(3, hiB, loB, hiA, loA, b0, b2, s0, S_OLD0)
+                BSVD_APF_TAP(4, hiA, loA, hiB, loB, b1, b0, s1, S_OLD1)
+                BSVD_APF_TAP(5, hiB, loB, hiA, loA, b2, b1, s2, S_OLD2)
+                BSVD_APF_TAP(6, hiA, loA, hiB, loB, b0, b2, s0, S_OLD0)
+                BSVD_APF_TAP(7, hiB, loB, hiA, loA, b1, b0, s1, S_OLD1)
+                BSVD_APF_TAP(8, hiA, loA, hiB, loB, b2, b1, s2, S_OLD2)
+#undef BSVD_APF_TAP
+                __syncthreads();
+            }
+        } else
         for (int cb = 0; cb < ncb; ++cb) {
             const float *pcur = patch_buf + (C::DBUF ? (cb & 1) * C::PATCH_FLOATS : 0);
             float *pnext = patch_buf + (C::DBUF ? ((cb + 1) & 1) * C::PATCH_FLOATS : 0);
@@ -597,16 +680,6 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                         if (tap >= BSVD_TUNE_D && tap <= C::NSLICE - 1 + BSVD_TUNE_D) slice_store(pnext, (tap - BSVD_TUNE_D) * C::ROWS_PER_SLICE, SOLD); \
                     ++step;                                                                                    \
                 }
-                // slice ring: loaded into slot tap%3, stored TWO taps later from slot (tap-2)%3 = (tap+1)%3
-#if BSVD_TUNE_D == 2
-#define S_OLD0 s1
-#define S_OLD1 s2
-#define S_OLD2 s0
-#else
-#define S_OLD0 s2
-#define S_OLD1 s0
-#define S_OLD2 s1
-#endif
                 if constexpr (C::RING == 3) {
                     BSVD_TAP(0, b0, b2, s0, S_OLD0)
                     BSVD_TAP(1, b1, b0, s1, S_OLD1)
