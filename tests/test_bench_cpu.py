@@ -1,0 +1,44 @@
+"""bench.py's host-side contract that can be checked without a GPU: the BASELINE workloads table, argument handling and the
+refusal modes (no GPU work is started here)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*argv, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, env=e, timeout=300)
+
+
+def test_workloads_cover_the_single_gpu_baseline_configs():
+    sys.path.insert(0, ROOT)
+    import bench
+    from bsvd_amd.netspec import make_netspec
+    assert sorted(bench.WORKLOADS) == ["c1", "c2", "c3", "c5"]
+    assert (bench.WORKLOADS["c1"]["h"], bench.WORKLOADS["c1"]["w"], bench.WORKLOADS["c1"]["frames"], bench.WORKLOADS["c1"]["mode"]) == (540, 960, 10, "clip")
+    assert (bench.WORKLOADS["c2"]["h"], bench.WORKLOADS["c2"]["w"], bench.WORKLOADS["c2"]["frames"]) == (480, 856, 85)
+    assert bench.WORKLOADS["c3"]["blind"] and not bench.WORKLOADS["c1"]["blind"]
+    assert (bench.WORKLOADS["c5"]["h"], bench.WORKLOADS["c5"]["w"], bench.WORKLOADS["c5"]["mode"]) == (1080, 1920, "perframe")
+    # FLOP per frame the JSON reports
+    c64 = make_netspec([64, 128, 256], 64, 4, 3, "relu6", 64)
+    assert 2 * c64.macs_per_frame(540, 960) == 1_227_239_424_000
+    assert abs(2 * c64.macs_per_frame(480, 856) / 1e12 - 0.9727) < 1e-3
+    assert abs(2 * c64.macs_per_frame(1080, 1920) / 1e12 - 4.909) < 1e-3
+    assert bench.usable_cores() >= 1
+
+
+def test_gpus_flag_must_match_the_launcher():
+    r = _run("--gpus", "2")
+    assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
+
+
+def test_stream_modes_refuse_more_than_one_rank():
+    # a live stream does not shard in time: replicas only; the refusal comes before any device work
+    r = _run("--gpus", "2", "--mode", "stream", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "single-GPU" in (r.stderr + r.stdout)
+    r = _run("--gpus", "3", "--scaling", "strong", "--total-frames", "80", env={"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "not divisible" in (r.stderr + r.stdout)
