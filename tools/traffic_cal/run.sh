@@ -1,5 +1,6 @@
 #!/bin/bash
-# On the GPU box: runs the FETCH_SIZE calibration (tools/traffic_cal/cal.hip, prebuilt as cal.bin in the container) under
+# On the GPU box: runs the FETCH_SIZE calibration (tools/traffic_cal/cal.hip; build it in the container first:
+#   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/traffic_cal/cal.hip -o tools/traffic_cal/cal.bin ) under
 # rocprofv3 and writes gpurun_out/traffic_calibration.json.   usage: tools/traffic_cal/run.sh
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/traffic_cal
