@@ -138,6 +138,14 @@ class _HipNet(nn.Module):
             ts = self.__dict__["_sig_tensors"] = list(self.parameters()) + list(self.buffers())
         return tuple((t.data_ptr(), t._version, t.device, t.dtype) for t in ts)
 
+    def extra_repr(self):
+        """what `print(model)` shows besides the parameter holders (profile.py:77 prints the model)"""
+        n = self.net
+        return ("MI355X engine: chns=%s mid_ch=%d in_ch=%d out_ch=%d act=%s interm_ch=%d blind=%s norm=%s precision=%s "
+                "(requested %s), %d fused conv layers / %d temporal-fusion, %.1f GMAC per 540x960 frame"
+                % (list(n.chns), n.mid_ch, n.net_in_ch, n.out_ch, n.act, n.interm_ch, n.blind, self.norm, self.precision,
+                   self.precision_requested, len(n.layers), n.shift_num, n.macs_per_frame(540, 960) / 1e9))
+
     def refresh_parameters(self):
         self.__dict__.pop("_sig_tensors", None)
 
