@@ -20,5 +20,5 @@ for src in conv3x3_mfma conv3x3_edge_f32 bsvd_abi; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -o "$OUT"
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$OBJ/conv3x3_mfma.o" "$OBJ/conv3x3_edge_f32.o" "$OBJ/bsvd_abi.o" -o "$OUT"
 echo "built $OUT"

@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from . import global_queue_buffer
-from .registry import MODEL_REGISTRY, build_network
+from .registry import _ENGINE, build_network, register_model
 
 
 def temp_denoise(model, noisyframe, sigma_noise, device=None):
@@ -85,22 +85,40 @@ def crop_padding(output, padding_list):
     return output[:, t1:f - t2, :, ph1:h - ph2, pw1:w - pw2]
 
 
-@MODEL_REGISTRY.register()
+def build_engine_network(net_opt):
+    """``build_network`` for the engine's own model class: a stock ``type`` (``BSVD`` / ``TSN``) always means the ENGINE's
+    class of that name, also while the reference plug-in holds the name in a shared BasicSR registry (then the engine's
+    class is registered as ``<type>_MI355X``, see registry.py); any other type goes through the registry."""
+    net_opt = dict(net_opt)
+    cls = _ENGINE["arch"].get(net_opt["type"])
+    if cls is None:
+        return build_network(net_opt)
+    net_opt.pop("type")
+    return cls(**net_opt)
+
+
+@register_model
 class DenoisingModel:
-    """Inference half of the reference's DenoisingModel: opt dict in, ``feed_data`` / ``test`` /
-    ``get_current_visuals`` out.  ``opt['network_g']`` is splatted into the arch constructor exactly like
-    basicsr.archs.build_network does; ``opt['val']['temp_psz']`` (-1 for BSVD) and ``future_buffer_len`` are
-    honoured; ``opt['num_gpu'] == 0`` is rejected (the engine is GPU-only)."""
+    """Inference half of the reference's DenoisingModel (denoising_model.py:16-190, 192-378): opt dict in, ``feed_data`` /
+    ``test`` / ``get_current_visuals`` and ``validation`` / ``dist_validation`` / ``nondist_validation`` (what
+    ``basicsr.test_pipeline`` calls, BasicSR/basicsr/test.py:37-41) out.  ``opt['network_g']`` is splatted into the arch
+    constructor exactly like basicsr.archs.build_network does; ``opt['val']['temp_psz']`` (-1 for BSVD) and
+    ``future_buffer_len`` are honoured.  The engine is GPU-only: without a HIP device construction raises."""
+
+    @staticmethod
+    def _pick_device():
+        if not torch.cuda.is_available():
+            raise RuntimeError("DenoisingModel needs a HIP device")
+        return torch.device("cuda")
 
     def __init__(self, opt):
         self.opt = opt
         self.is_train = bool(opt.get("is_train", False))
         if self.is_train:
             raise NotImplementedError("bsvd_amd implements the inference path only (training is out of scope)")
-        if not torch.cuda.is_available():
-            raise RuntimeError("DenoisingModel needs a HIP device")
-        self.device = torch.device("cuda")
-        self.net_g = build_network(opt["network_g"]).to(self.device)
+        self.device = self._pick_device()
+        self.center_frame_only = bool(opt.get("center_frame_only", False))
+        self.net_g = build_engine_network(opt["network_g"]).to(self.device)
         popt = opt.get("path") or {}
         if popt.get("pretrain_network_g"):
             self.load_network(self.net_g, popt["pretrain_network_g"], popt.get("strict_load_g", True),
@@ -153,3 +171,103 @@ class DenoisingModel:
         if self.gt is not None:
             out["gt"] = self.gt.detach().cpu()
         return out
+
+    # ---- what basicsr.test_pipeline drives (BasicSR/basicsr/test.py:37-41) ----------------------------------------
+    def validation(self, dataloader, current_iter, tb_logger, save_img=False):
+        """denoising_model.py:192-209.  ``val.fp16`` put the reference's convs under autocast; the engine's arithmetic is
+        fixed by ``network_g.precision`` (split-fp16 3-pass or exact fp32, both fp32-class), so the flag only logs."""
+        if self.opt.get("dist", False):
+            return self.dist_validation(dataloader, current_iter, tb_logger, save_img)
+        if (self.opt.get("val") or {}).get("fp16", False):
+            _logger().info("val.fp16 is set: the MI355X engine keeps its own arithmetic (precision=%s)",
+                           getattr(self.net_g, "precision", "?"))
+        return self.nondist_validation(dataloader, current_iter, tb_logger, save_img)
+
+    def dist_validation(self, dataloader, current_iter, tb_logger, save_img):
+        """denoising_model.py:211-213: rank 0 evaluates, the others return None."""
+        if self.opt.get("rank", 0) == 0:
+            return self.nondist_validation(dataloader, current_iter, tb_logger, save_img)
+        return None
+
+    def nondist_validation(self, dataloader, current_iter, tb_logger, save_img):
+        """denoising_model.py:215-323: every folder of ``dataloader.dataset`` through feed_data / test, per-frame metrics
+        of ``val.metrics`` into ``self.metric_results[folder]`` ([frames, metrics]), optional PNG dump under
+        ``path.visualization/<dataset>/<folder>/<idx:08d>_<name>.png``, then the log line / CSVs of
+        ``_log_validation_metric_values``.  Returns {metric: mean over folders}."""
+        import os
+        from . import evaluation
+        dataset = dataloader.dataset if hasattr(dataloader, "dataset") else dataloader
+        dataset_name = dataset.opt["name"]
+        val = self.opt.get("val") or {}
+        metrics = val.get("metrics")
+        with_metrics = metrics is not None
+        if with_metrics:
+            self.metric_results = {folder: torch.zeros(dataset.num_frames[i], len(metrics), dtype=torch.float32)
+                                   for i, folder in enumerate(dataset.base_folder)}
+        total = None
+        for i in range(len(dataset)):
+            val_data = dataset[i]
+            folder = val_data["folder"]
+            self.feed_data(val_data)
+            with torch.no_grad():
+                self.test()
+            visuals = self.get_current_visuals()
+            self.lq = self.output = self.noise_map = self.gt = None      # "tentative for out of GPU memory" (:259-265)
+            res = visuals["result"][0]
+            gt = None
+            if "gt" in visuals:
+                gt = visuals["gt"][0] if visuals["gt"].dim() == 5 else visuals["gt"]
+            for idx in range(res.shape[0]):
+                if save_img:
+                    path = os.path.join(self.opt["path"]["visualization"], dataset_name, folder,
+                                        "%08d_%s.png" % (idx, self.opt.get("name", "bsvd")))
+                    evaluation.imwrite(evaluation.tensor2img(res[idx]), path)
+                if with_metrics and gt is not None:
+                    vals = evaluation.frame_metrics(res[idx], gt[idx], metrics)
+                    for mi, name in enumerate(metrics):
+                        self.metric_results[folder][idx, mi] += vals[name]
+            if with_metrics:
+                total = self._log_validation_metric_values(current_iter, dataset_name, tb_logger)
+        return total
+
+    def _log_validation_metric_values(self, current_iter, dataset_name, tb_logger):
+        """denoising_model.py:325-367: per-folder means, mean over folders, the reference's log line, one CSV of per-frame
+        values per folder next to the log file (columns ``<folder>_<metric index>``), tensorboard scalars."""
+        metrics = list((self.opt.get("val") or {}).get("metrics").keys())
+        avg = {folder: t.mean(dim=0) for folder, t in self.metric_results.items()}
+        log = _logger()
+        base = _log_file(log)
+        if base is not None:
+            for folder, t in self.metric_results.items():
+                with open(base.replace(".log", "%s.csv" % folder), "w") as fh:
+                    fh.write("," + ",".join("%s_%d" % (folder, mi) for mi in range(len(metrics))) + "\n")
+                    for r in range(t.shape[0]):
+                        fh.write("%d," % r + ",".join(str(t[r, mi].numpy()) for mi in range(len(metrics))) + "\n")
+        total = {m: sum(float(a[mi]) for a in avg.values()) / max(len(avg), 1) for mi, m in enumerate(metrics)}
+        msg = "Validation %s\n" % dataset_name
+        for mi, (metric, value) in enumerate(total.items()):
+            msg += "\t # %s: %.4f" % (metric, value)
+            for folder, a in avg.items():
+                msg += "\t # %s: %.4f" % (folder, float(a[mi]))
+            msg += "\n"
+        log.info(msg)
+        if tb_logger:
+            for mi, (metric, value) in enumerate(total.items()):
+                tb_logger.add_scalar("metrics/%s" % metric, value, current_iter)
+                for folder, a in avg.items():
+                    tb_logger.add_scalar("metrics/%s/%s" % (metric, folder), float(a[mi]), current_iter)
+        return total
+
+
+def _logger():
+    """basicsr.utils.get_root_logger's logger (name 'basicsr'); test_pipeline attaches the stream + file handlers."""
+    import logging
+    return logging.getLogger("basicsr")
+
+
+def _log_file(log):
+    import logging
+    for h in log.handlers:
+        if isinstance(h, logging.FileHandler):
+            return h.baseFilename
+    return None

@@ -13,15 +13,19 @@ of clips + a checkpoint into the PSNR/SSIM table of the paper.
                                  per-frame metrics, per-folder mean, mean over folders.
 
 Image decoding uses PIL (cv2 is not available here); cv2.imread's BGR + cvtColor(BGR2RGB) equals PIL's RGB.
-PSNR is pinned to the reference by tests/golden/g9_psnr.npz.  SSIM needs cv2 in the reference and cannot be run in
-the build container; it is restated from the formula (11x11 gaussian, sigma 1.5, 'valid' window) and tested against an
-independent direct implementation.
+PSNR is pinned to the reference by tests/golden/g9_psnr.npz (the reference's own metric functions).  SSIM is NOT pinned
+to cv2: the reference's ``_ssim`` needs ``cv2.getGaussianKernel`` / ``cv2.filter2D``, cv2 is absent from the build
+container, and golden g12 runs the reference's formula over numpy STAND-INS for those two calls -- it pins the formula
+and this restatement (11x11 gaussian, sigma 1.5, 'valid' window; also tested against an independent direct window sum),
+not OpenCV's arithmetic.
 """
 import glob
 import os
 
 import numpy as np
 import torch
+
+from .registry import register_dataset
 
 IMAGETYPES = ('*.bmp', '*.png', '*.jpg', '*.jpeg', '*.tif')
 
@@ -47,8 +51,11 @@ def open_sequence(seq_dir, max_num_fr=100):
     return np.float32(np.stack(frames, 0) / 255.)
 
 
+@register_dataset
 class ValFolderDataset:
-    """opt keys like the reference: valsetdir, num_validation_frames, valnoisestd, [scene_name], [blind], [name]."""
+    """opt keys like the reference: valsetdir, num_validation_frames, valnoisestd, [scene_name], [blind], [name].
+    In DATASET_REGISTRY (video_dali_dataset.py:199-200), so ``basicsr.data.build_dataset`` finds it; an instance is what
+    ``DenoisingModel.nondist_validation`` reads through ``dataloader.dataset`` (opt['name'], base_folder, num_frames)."""
 
     def __init__(self, opt, device=None):
         self.opt = opt
@@ -165,6 +172,31 @@ def calculate_ssim(img, img2, crop_border, input_order='HWC', test_y_channel=Fal
 METRICS = {"calculate_psnr": calculate_psnr, "calculate_psnr_float": calculate_psnr_float, "calculate_ssim": calculate_ssim}
 
 
+def frame_metrics(result, gt, metrics_opt):
+    """{name: value} of one frame pair ([3,H,W] float tensors): 'float' metrics on the tensors, the others on the uint8
+    BGR images ``tensor2img`` makes of them (denoising_model.py:275-310, basicsr/metrics/__init__.py calculate_metric)."""
+    out = {}
+    imgs = None
+    for name, mo in metrics_opt.items():
+        mo = dict(mo)
+        typ = mo.pop('type')
+        fn = METRICS[typ]
+        if 'float' in typ:
+            out[name] = fn(result, gt, **mo)
+        else:
+            if imgs is None:
+                imgs = (tensor2img(result), tensor2img(gt))
+            out[name] = fn(imgs[0], imgs[1], **mo)
+    return out
+
+
+def imwrite(img_bgr, path):
+    """basicsr.utils.imwrite (cv2.imwrite of a BGR uint8 image, parent directory created) on PIL."""
+    from PIL import Image
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    Image.fromarray(img_bgr[..., ::-1] if img_bgr.ndim == 3 else img_bgr).save(path)
+
+
 def evaluate(model, dataset, metrics_opt, per_frame=None, save_img_dir=None, run_name="bsvd"):
     """model: bsvd_amd.DenoisingModel; metrics_opt: {name: {type: calculate_psnr, crop_border: 2}, ...} as in
     options/test/bsvd_c64.yml:116-123.  Returns ({folder: {metric: mean}}, {metric: mean over folders}).
@@ -180,21 +212,13 @@ def evaluate(model, dataset, metrics_opt, per_frame=None, save_img_dir=None, run
         res, gt = vis['result'][0], vis['gt'][0] if vis['gt'].dim() == 5 else vis['gt']
         acc = {k: [] for k in metrics_opt}
         for f in range(res.shape[0]):
-            for name, mo in metrics_opt.items():
-                mo = dict(mo)
-                fn = METRICS[mo.pop('type')]
-                if fn is calculate_psnr_float:
-                    acc[name].append(fn(res[f], gt[f], **mo))
-                else:
-                    acc[name].append(fn(tensor2img(res[f]), tensor2img(gt[f]), **mo))
+            for name, v in frame_metrics(res[f], gt[f], metrics_opt).items():
+                acc[name].append(v)
         per_folder[item['folder']] = {k: float(np.mean(v)) for k, v in acc.items()}
         if per_frame is not None:
             per_frame[item['folder']] = acc
         if save_img_dir is not None:
-            from PIL import Image
-            d = os.path.join(save_img_dir, item['folder'])
-            os.makedirs(d, exist_ok=True)
             for f in range(res.shape[0]):
-                Image.fromarray(tensor2img(res[f], rgb2bgr=False)).save(os.path.join(d, "%08d_%s.png" % (f, run_name)))
+                imwrite(tensor2img(res[f]), os.path.join(save_img_dir, item['folder'], "%08d_%s.png" % (f, run_name)))
     total = {k: float(np.mean([v[k] for v in per_folder.values()])) for k in metrics_opt} if per_folder else {}
     return per_folder, total

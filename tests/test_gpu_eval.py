@@ -182,3 +182,60 @@ def test_live_stream_uint8_frames_match_the_clip_path(depth):
         assert np.array_equal(np.stack(got), want)
     with pytest.raises(ValueError):
         live.feed(np.zeros((30, 50, 3), np.uint8))
+
+
+def test_validation_through_the_test_pipeline_calls(tmp_path):
+    """What basicsr.test_pipeline does with a model (BasicSR/basicsr/test.py:26-41): build_dataset, a batch-1 DataLoader,
+    build_model, model.validation(loader, current_iter=name, tb_logger=None, save_img=...) -- on the HIP engine, with the
+    per-folder CSVs next to the log file and the PNG dump of val.save_img (denoising_model.py:192-367)."""
+    import logging
+    from PIL import Image
+    import bsvd_amd
+    from bsvd_amd import evaluation as E
+    rs = np.random.RandomState(9)
+    for clip, n in (("a", 3), ("b", 2)):
+        os.makedirs(tmp_path / "data" / clip)
+        for i in range(n):
+            Image.fromarray(rs.randint(0, 256, (30, 50, 3)).astype(np.uint8)).save(tmp_path / "data" / clip / ("%03d.png" % i))
+    opt = {"name": "run3", "model_type": "DenoisingModel", "num_gpu": 1, "dist": False, "rank": 0,
+           "network_g": {"type": "BSVD", "chns": [32, 64, 128], "mid_ch": 32, "shift_input": False, "norm": "none",
+                         "interm_ch": 32, "act": "relu6", "pretrain_ckpt": None},
+           "path": {"visualization": str(tmp_path / "vis")},
+           "val": {"temp_psz": -1, "save_img": True,
+                   "metrics": {"psnr": {"type": "calculate_psnr", "crop_border": 2},
+                               "psnr_float": {"type": "calculate_psnr_float", "crop_border": 2}}}}
+    dopt = {"name": "syn", "type": "ValFolderDataset", "valsetdir": str(tmp_path / "data"), "num_validation_frames": 85,
+            "valnoisestd": 30, "phase": "val"}
+    bsvd_amd.install(replace=True)
+    log = logging.getLogger("basicsr")
+    old = list(log.handlers)
+    fh = logging.FileHandler(tmp_path / "test_run3.log")
+    log.addHandler(fh)
+    log.setLevel(logging.INFO)
+    try:
+        torch.manual_seed(10)
+        ds = bsvd_amd.build_dataset(dopt)
+        loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, num_workers=0)
+        model = bsvd_amd.build_model(opt)
+        assert isinstance(model.net_g, bsvd_amd.BSVD)
+        total = model.validation(loader, current_iter=opt["name"], tb_logger=None, save_img=opt["val"]["save_img"])
+    finally:
+        log.removeHandler(fh)
+        fh.close()
+        assert log.handlers == old
+    assert set(total) == {"psnr", "psnr_float"} and all(np.isfinite(v) for v in total.values())
+    text = (tmp_path / "test_run3.log").read_text()
+    assert "Validation syn\n\t # psnr: %.4f" % total["psnr"] in text
+    rows = (tmp_path / "test_run3a.csv").read_text().strip().splitlines()
+    assert rows[0] == ",a_0,a_1" and len(rows) == 4
+    assert sorted(os.listdir(tmp_path / "vis" / "syn" / "b")) == ["%08d_run3.png" % i for i in range(2)]
+    # the same numbers through the stand-alone evaluate() with the same noise realisation
+    torch.manual_seed(10)
+    model2 = bsvd_amd.build_model(opt)
+    model2.net_g.load_state_dict(model.net_g.state_dict())
+    torch.manual_seed(10)
+    bsvd_amd.BSVD(**{k: v for k, v in opt["network_g"].items() if k != "type"})      # same RNG consumption as build_model
+    per_folder, tot2 = E.evaluate(model2, bsvd_amd.build_dataset(dopt), opt["val"]["metrics"])
+    assert abs(tot2["psnr"] - total["psnr"]) < 1e-4 and set(per_folder) == {"a", "b"}
+    img = np.asarray(Image.open(tmp_path / "vis" / "syn" / "a" / "00000000_run3.png"))
+    assert img.shape == (30, 50, 3)

@@ -361,10 +361,10 @@ def test_denoising_model_pad_clamp_crop_end_to_end():
     from oracle import bsvd_oracle as O
     st = seeded_state(bsvd_keys([32, 64, 128], 32, 4, 3, 32), 21)
     opt = {"is_train": False, "num_gpu": 1, "val": {"temp_psz": -1},
-           "network_g": {"type": "BSVD" if "BSVD" in bsvd_amd.ARCH_REGISTRY else "BSVD_MI355X", "chns": [32, 64, 128],
+           "network_g": {"type": "BSVD", "chns": [32, 64, 128],
                          "mid_ch": 32, "shift_input": False, "in_ch": 4, "out_ch": 3, "norm": "none", "act": "relu6",
                          "interm_ch": 32, "blind": False, "pretrain_ckpt": None}}
-    model = bsvd_amd.MODEL_REGISTRY.get("DenoisingModel")(opt)
+    model = bsvd_amd.MODEL_REGISTRY.get("DenoisingModel_MI355X")(opt)
     model.net_g.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
     rs = np.random.RandomState(22)
     gt = torch.from_numpy(rs.uniform(0, 1, (6, 3, 30, 50)).astype(np.float32))

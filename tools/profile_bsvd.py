@@ -24,7 +24,8 @@ ap.add_argument("--trace", default=None, metavar="FILE.json",
                      "and export a chrome trace; the hand-written kernels show up under their own names")
 args = ap.parse_args()
 
-name = "BSVD" if "BSVD" in bsvd_amd.ARCH_REGISTRY else "BSVD_MI355X"
+bsvd_amd.install(replace=True)
+name = "BSVD"
 net = bsvd_amd.build_network(dict(type=name, chns=[64, 128, 256], mid_ch=64, shift_input=False, in_ch=4, out_ch=3,
                                   norm="none", act="relu6", interm_ch=64, blind=False, pretrain_ckpt=None,
                                   engine_mode=args.mode, precision=args.precision)).cuda().eval()

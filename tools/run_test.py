@@ -46,8 +46,7 @@ def main():
     if seed is not None:                       # basicsr.utils.set_random_seed
         random.seed(seed); np.random.seed(seed); torch.manual_seed(seed); torch.cuda.manual_seed_all(seed)
     net_opt = opt["network_g"]
-    if net_opt["type"] not in bsvd_amd.ARCH_REGISTRY and net_opt["type"] + "_MI355X" in bsvd_amd.ARCH_REGISTRY:
-        net_opt["type"] += "_MI355X"
+    bsvd_amd.install(replace=True)             # the stock names of the YAML (BSVD / TSN / DenoisingModel) -> the engine
     if args.precision:
         net_opt["precision"] = args.precision
     if net_opt.get("pretrain_ckpt") and not os.path.exists(net_opt["pretrain_ckpt"]):
