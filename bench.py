@@ -375,6 +375,14 @@ def main():
         t_max = torch.tensor([dt], dtype=torch.float64)
         if dist is not None:
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+            # self-diagnosing N > 1 line: what every rank actually exchanged (16 temporal-fusion layers per forward; interior
+            # ranks send 2 slices per layer, the outermost ranks 1) and how long its own steps took
+            mine = {"rank": rank, "device": torch.cuda.get_device_name(device), "exchanges": halo_fn.exchanges,
+                    "bytes_sent": halo_fn.bytes_sent, "host_staged": bool(halo_fn.host_staging), "timed_s": dt,
+                    "forwards": halo_fn.exchanges // 16}
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            model.bench_halo_stats = gathered
         return model, float(t_max.item()), agg, y
 
     def roofline_of(agg, precision, steps):
@@ -460,6 +468,11 @@ def main():
         }
         if stream_stats:
             out["stream_engine"] = stream_stats
+        if world > 1:
+            out["halo"] = {"transport": halo_transport, "degraded": degraded,
+                           "expected": "16 exchanges per forward and rank; per forward an interior rank sends 2 x 99.5 MB (fp32 / "
+                                       "split16 alike), the first and last rank 1 x 99.5 MB at 540x960",
+                           "per_rank": getattr(model, "bench_halo_stats", None)}
         if world == 1 and not args.no_cpu_baseline:
             # bounded sample of the same workload: 10 frames of its geometry (4 at 1080p), the CPU path's cost is linear in frames
             out["cpu_baseline"] = cpu_baseline(model, h, w, wl["blind"], frames=4 if h * w > 540 * 960 else 10)

@@ -9,6 +9,8 @@ the C ABI (include/bsvd_hip.h).  The module tree only HOLDS the parameters (so `
 """
 from collections import OrderedDict
 
+import warnings
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -17,6 +19,23 @@ from . import checkpoint
 from .netspec import clip_peak_bytes, make_netspec, norm_key_after
 from .registry import register_arch
 from .schedule import StreamPipeline, bsvd_clip, planar_ok
+
+
+# Any (re-)registration of a Parameter, buffer or sub-module anywhere in the process bumps this counter; the engines cache
+# their parameter list against it, so ``module.weight = nn.Parameter(...)``, prune / parametrize or a swapped sub-module
+# are noticed at the next forward without walking the module tree on every call.
+_REGISTRATION_EPOCH = [0]
+
+
+def _bump_epoch(*_args, **_kwargs):
+    _REGISTRATION_EPOCH[0] += 1
+
+
+for _hook in ("register_module_parameter_registration_hook", "register_module_buffer_registration_hook",
+              "register_module_module_registration_hook"):
+    getattr(torch.nn.modules.module, _hook)(_bump_epoch)
+
+F16X3_WEIGHT_LIMIT = 6.0e4      # |folded weight| beyond this cannot be carried as an fp16 pair (fp16 max 65504)
 
 
 class _Slots(nn.Module):
@@ -125,18 +144,24 @@ class _HipNet(nn.Module):
         BatchNorm of every conv folded in."""
         st = self._bsvd_state()
         if self.norm == "bn":
-            st = checkpoint.fold_batchnorm(st, [l.key for l in self.net.layers], norm_key_after)
+            eps = {name: m.eps for name, m in self._bsvd_modules() if isinstance(m, nn.BatchNorm2d)}
+            st = checkpoint.fold_batchnorm(st, [l.key for l in self.net.layers], norm_key_after, eps)
         return st
+
+    def _bsvd_modules(self):
+        """(name in BSVD key space, module) pairs -- TSN overrides the name mapping"""
+        return self.named_modules()
 
     def _signature(self):
         """Identity + version of every parameter AND buffer (BatchNorm running statistics): any in-place update, device move or
         dtype change re-packs the weights.  Called on every forward / feed, so the tensor list is cached -- walking the module
-        tree cost 0.4 ms per call, 2/3 of the host time of a graph-replayed feedin_one_element.  ``_apply`` (``.to()``,
-        ``.half()``, ``.cuda()``) drops the cache; code that swaps Parameter OBJECTS by hand calls ``refresh_parameters()``."""
-        ts = self.__dict__.get("_sig_tensors")
-        if ts is None:
-            ts = self.__dict__["_sig_tensors"] = list(self.parameters()) + list(self.buffers())
-        return tuple((t.data_ptr(), t._version, t.device, t.dtype) for t in ts)
+        tree cost 0.4 ms per call, 2/3 of the host time of a graph-replayed feedin_one_element.  The cache is keyed by the
+        process-wide registration epoch (torch's global parameter / buffer / module registration hooks), so replacing a
+        Parameter object, pruning or swapping a sub-module invalidates it; ``_apply`` and ``load_state_dict`` drop it too."""
+        cached = self.__dict__.get("_sig_tensors")
+        if cached is None or cached[0] != _REGISTRATION_EPOCH[0]:
+            cached = self.__dict__["_sig_tensors"] = (_REGISTRATION_EPOCH[0], list(self.parameters()) + list(self.buffers()))
+        return tuple((t.data_ptr(), t._version, t.device, t.dtype) for t in cached[1])
 
     def extra_repr(self):
         """what `print(model)` shows besides the parameter holders (profile.py:77 prints the model)"""
@@ -170,7 +195,23 @@ class _HipNet(nn.Module):
             # BEFORE the old pack is freed (a new executor may even reuse the old one's id())
             if getattr(self, "_stream_engs", None):
                 self.release_stream_buffers()
-            self._packed = PackedNet(self.net, self._engine_state(), device, self.precision)
+            state = self._engine_state()
+            if self.precision == "f16x3":
+                # fp16 range guard of the split mode: a folded weight (norm='bn' with a tiny running_var) beyond fp16's range
+                # cannot be carried as a hi+lo pair.  'auto' falls back to exact fp32, an explicit 'f16x3' refuses.
+                # (Activations beyond +-65504 saturate in the split store; unbounded-ReLU networks fed [0,1] images stay
+                # orders of magnitude below that)
+                wmax = max(float(state[l.key + ".weight"].abs().max()) for l in self.net.layers)
+                if not wmax <= F16X3_WEIGHT_LIMIT:
+                    if self.precision_requested == "auto":
+                        warnings.warn("bsvd_amd: max |weight| after the BatchNorm fold is %.3g, outside fp16's range: "
+                                      "precision='auto' falls back to exact fp32 for this network" % wmax)
+                        self.precision = "fp32"
+                        sig = (sig[0], sig[1], self.precision)
+                    else:
+                        raise ValueError("precision='f16x3': max |weight| after the BatchNorm fold is %.3g, outside fp16's "
+                                         "range (use precision='fp32' or 'auto')" % wmax)
+            self._packed = PackedNet(self.net, state, device, self.precision)
             self._packed_sig = sig
             self._exec = HipExecutor(self._packed)
             self._exec_gen = getattr(self, "_exec_gen", 0) + 1
@@ -318,8 +359,18 @@ class BSVD(_HipNet):
             from .stream_plan import StreamEngine
             for other in [c for c in self._stream_engs if c != 1 and c != chunk]:     # keep the per-frame engine + one chunked
                 self._stream_engs.pop(other).release()
-            eng = self._stream_engs[chunk] = StreamEngine(self.net, ex, frame_shape[1], frame_shape[2], frame_shape[0],
-                                                          chunk=chunk, use_graphs=self.stream_graphs)
+            if (key, chunk) in self.__dict__.setdefault("_ring_oom", set()):
+                return None                      # this configuration already failed to allocate: do not retry per frame
+            try:
+                eng = StreamEngine(self.net, ex, frame_shape[1], frame_shape[2], frame_shape[0], chunk=chunk,
+                                   use_graphs=self.stream_graphs)
+            except torch.cuda.OutOfMemoryError:
+                self._ring_oom.add((key, chunk))
+                # the rings did not fit after all (another tenant of the device, fragmentation): the caller retries with a
+                # smaller chunk and finally takes the allocating frame-by-frame pipeline, whose footprint is smaller still
+                torch.cuda.empty_cache()
+                return None
+            self._stream_engs[chunk] = eng
         return eng
 
     def _pick_chunk(self, F, H, W):
@@ -429,8 +480,16 @@ class BSVD(_HipNet):
             pin, pout = planar_ok(ex, self.net)
             if not (pin and pout and self.stream_rings):
                 return None
+            for f in input_seq:
+                if f.shape != x0.shape:          # slot.copy_() would broadcast a [1,C,1,1] or [1,1,H,W] frame silently
+                    raise ValueError("streaming_forward: frames of different shapes %s / %s" % (tuple(x0.shape), tuple(f.shape)))
             n = self._pick_chunk(F, x0.shape[-2], x0.shape[-1])
             eng = self._stream_engine(ex, x0.shape[1:], n)
+            while eng is None and n > 1:         # ring allocation ran out of memory: halve the chunk
+                n //= 2
+                eng = self._stream_engine(ex, x0.shape[1:], n)
+            if eng is None:
+                return None                      # -> the allocating frame-by-frame pipeline of streaming_forward
             out_dtype = x0.dtype if x0.dtype in (torch.float16, torch.bfloat16) else torch.float32
             ypl = (self.net.out_ch, self.clamp)
             out = torch.empty((F, self.net.out_ch) + tuple(x0.shape[-2:]), dtype=out_dtype, device=dev)
@@ -474,10 +533,24 @@ class BSVD(_HipNet):
         frames of 1080p -- fits 288 GB; 4K does not); the stream schedule holds a fixed number of frames."""
         if self.engine_mode != "auto":
             return self.engine_mode
+        need = clip_peak_bytes(self.net, frames, H, W)
+        # decided once per geometry while nothing else changed the picture: a clip schedule that fitted keeps fitting as long
+        # as this model holds no more ring memory than it did then (the memory query costs ~50 us per call otherwise)
+        held = sum(e.ring_bytes for e in self._stream_engs.values())
+        cached = self.__dict__.get("_mode_cache")
+        if cached is not None and cached[0] == (frames, H, W, held):
+            return cached[1]
         dev = self._device()
         free, _ = torch.cuda.mem_get_info(dev)
         free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)     # cached by torch, reusable
-        return "clip" if clip_peak_bytes(self.net, frames, H, W) <= 0.9 * free else "stream"
+        mode = "clip" if need <= 0.9 * free else "stream"
+        if mode == "stream" and held and need <= 0.9 * (free + held):
+            # the rings a previous streaming_forward / feedin_one_element left behind are what stands in the way: give them back
+            self.release_stream_buffers()
+            torch.cuda.empty_cache()
+            mode, held = "clip", 0
+        self.__dict__["_mode_cache"] = ((frames, H, W, held), mode)
+        return mode
 
     def count_shift(self):
         return self.net.shift_num
@@ -567,6 +640,11 @@ class TSN(_HipNet):
 
     def _bsvd_state(self):
         return checkpoint.to_bsvd_state(self.state_dict())
+
+    def _bsvd_modules(self):
+        for name, m in self.named_modules():
+            if isinstance(m, nn.BatchNorm2d):
+                yield checkpoint.tsn_key_to_bsvd(name + ".weight")[:-len(".weight")], m
 
     def forward(self, input, noise_map=None):
         five_d = input.dim() == 5

@@ -53,7 +53,9 @@ def fold_batchnorm(state, layer_keys, norm_key_after, eps=1e-5):
     """Eval-mode BatchNorm2d folded into the preceding conv (one-time, at weight-pack time): with
     s = gamma / sqrt(running_var + eps):  w' = w * s[:, None, None, None],  b' = (b - running_mean) * s + beta.
     Covers the reference's default ``norm='bn'`` (get_norm_function, bsvd_arch.py:176-183; BN sits right after the conv,
-    before the activation, :122-130, 207-216, 237-241, 294-298).  Returns a state with conv keys only."""
+    before the activation, :122-130, 207-216, 237-241, 294-298).  ``eps``: a float, or {norm key: that BatchNorm2d's eps}.
+    Returns a state with conv keys only."""
+    eps_of = (lambda k: eps.get(k, 1e-5)) if isinstance(eps, dict) else (lambda k: eps)
     out = OrderedDict()
     for key in layer_keys:
         w, b = state[key + ".weight"].detach().float(), state[key + ".bias"].detach().float()
@@ -61,7 +63,7 @@ def fold_batchnorm(state, layer_keys, norm_key_after, eps=1e-5):
         if nk is not None and nk + ".running_mean" in state:
             mean, var = state[nk + ".running_mean"].detach().float(), state[nk + ".running_var"].detach().float()
             gamma, beta = state[nk + ".weight"].detach().float(), state[nk + ".bias"].detach().float()
-            s_ = (gamma.double() / torch.sqrt(var.double() + eps))
+            s_ = (gamma.double() / torch.sqrt(var.double() + eps_of(nk)))
             w = (w.double() * s_[:, None, None, None]).float()
             b = ((b.double() - mean.double()) * s_ + beta.double()).float()
         out[key + ".weight"], out[key + ".bias"] = w, b

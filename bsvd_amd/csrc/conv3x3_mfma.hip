@@ -56,6 +56,20 @@
 #ifndef BSVD_TUNE_APF
 #define BSVD_TUNE_APF 1        // split DBUF tiles that request the NEXT tap's pixel fragments in the middle of the current tap: 0 none, 1 the exit tile (NT == 1), 2 all, 3 fat tiles
 #endif
+#ifndef BSVD_TUNE_QPL
+#define BSVD_TUNE_QPL 3        // quad-planar LDS patch ([row][16-B channel quad][column], row pitch a multiple of 256 B): bit 0 the 256-px tiles
+                               // (64-channel layers, exit layer), bit 1 the stride-2 tile (even / odd columns in separate planes), bit 2 the
+                               // 128-channel stride-1 tiles (which already read conflict-free from the padded 80-B layout at a 1536-B pitch)
+#endif
+#ifndef BSVD_TUNE_PRIO
+#define BSVD_TUNE_PRIO 0       // s_setprio experiment: 1 = epilogue at priority 2, 2 = prologue + epilogue at priority 2, 3 = K loop at priority 2
+#endif
+#ifndef BSVD_TUNE_MIXLO
+#define BSVD_TUNE_MIXLO 2      // split epilogue: lo halves by v_fma_mix{lo,hi}_f16: 0 never (cvt + sub + cvt_pk), 1 always, 2 the 64-accumulator tiles
+#endif
+#ifndef BSVD_TUNE_S2_DBUF
+#define BSVD_TUNE_S2_DBUF 0    // 1: split-fp16 stride-2 tile with a double-buffered (swizzled) patch at 2 workgroups per CU
+#endif
 #ifndef BSVD_TUNE_D
 #define BSVD_TUNE_D 1          // patch slices stored D (1|2) taps after their load was issued
 #endif
@@ -91,15 +105,37 @@ struct ConvCfg {
     static constexpr int BN = WN * NT * 32;
     static constexpr int PH = (TH - 1) * STRIDE + 3;
     static constexpr int PW = (TW - 1) * STRIDE + 3;
-    static constexpr int PS = 20;                      // floats per patch pixel
+    // LDS patch layout.  Padded (the original): [row][column][16 ch + 4 pad] floats -- the 80-B pixel pitch spreads the 16
+    // columns of a row over all sixteen 16-B slots of a 256-B bank row, but the two rows of a ds_read_b128 lane group only
+    // complement each other when the row pitch is a multiple of 256 B, and that pitch did not fit the 256-px tile three
+    // times into 160 KiB (r02 PMC: 46-49 % of the LDS cycles of the 64-channel, exit and stride-2 tiles were bank conflicts).
+    // Quad-planar (QPL): [row][channel quad q = 0..3][column] x 16 B, row pitch a multiple of 256 B.  A lane group reads ONE
+    // quad of 8 pixels of row r (columns 0-3, 12-15 + kx) and 8 of row r+1 (columns 4-11 + kx): sixteen consecutive 16-B slots,
+    // conflict-free for every tap; a tap's kx and the hi/lo quad are immediate offsets.  The staging writes are conflict-free
+    // too: 8 adjacent lanes = 2 columns x 4 quads, and the 288-B (stride 2: 272-B) plane pitch puts the quads 32 B (16 B)
+    // apart modulo the 128-B write bank row.  64 B per pixel instead of 80: 4/5 of the padded layout's LDS.  Stride 2: a tap
+    // reads every other column, so even and odd columns get separate planes ([row][quad][parity][column / 2]).
+    static constexpr bool QPL = (STRIDE == 2) ? (BSVD_TUNE_QPL & 2) != 0
+                                              : ((MT == 2 && WM == 4) ? (BSVD_TUNE_QPL & 1) != 0 : (BSVD_TUNE_QPL & 4) != 0);
+    static constexpr int PS = QPL ? 16 : 20;           // floats per patch pixel
+    static constexpr int PLANE = STRIDE == 2 ? ((PW + 1) / 2) * 4 : PW * 4;      // QPL: floats per (quad[, parity]) plane of a row
     static constexpr int NP = PH * PW;                 // patch pixels
     static constexpr int NQ = NP * 4;                  // float4 items per patch chunk
     // LDS row pitch of the patch.  Stride 1: rounded up to a multiple of 256 B so that the two pixel rows one
     // ds_read_b128 lane group touches land on complementary 16-B slots (conflict-free A reads; PMC showed 48 % of the
     // LDS cycles were bank conflicts with the packed 1440-B pitch).  Not for the 256-px x 64-ch tile at 3 workgroups
     // per CU, whose double-buffered patch would no longer fit three times into 160 KiB.
-    static constexpr bool ALIGN_ROWS = BSVD_TUNE_ALIGN && STRIDE == 1 && !(MT == 2 && WM == 4);
+    static constexpr bool ALIGN_ROWS = QPL || (BSVD_TUNE_ALIGN && STRIDE == 1 && !(MT == 2 && WM == 4));
     static constexpr int ROWP = ALIGN_ROWS ? ((PW * PS * 4 + 255) / 256 * 256) / 4 : PW * PS;   // floats
+    // float offset of the 16-B channel quad `quad` of patch pixel (prow, pcol)
+    __host__ __device__ static constexpr int lds_off(int prow, int pcol, int quad)
+    {
+        if (!QPL) return prow * ROWP + pcol * PS + quad * 4;
+        if (STRIDE == 2) return prow * ROWP + (quad * 2 + (pcol & 1)) * PLANE + (pcol >> 1) * 4;
+        return prow * ROWP + quad * PLANE + pcol * 4;
+    }
+    // ... and of tap column kx / operand half g (0: quads 0-1 = fp32 channels 0-7 or the hi halves, 1: quads 2-3) relative to it
+    __host__ __device__ static constexpr int tap_off(int kx, int g) { return lds_off(0, kx, 2 * g); }
     static constexpr int PATCH_FLOATS = PH * ROWP;
     static constexpr int LDS_BYTES = (DBUF ? 2 : 1) * PATCH_FLOATS * 4 < 4 * 32 * 36 * 4 ? 4 * 32 * 36 * 4
                                                                                           : (DBUF ? 2 : 1) * PATCH_FLOATS * 4;
@@ -171,7 +207,7 @@ __device__ __forceinline__ void store_patch_quad(float *patch, int e, f32x4 v)
 {
     const int pix = e >> 2, q = e & 3;
     const int py = pix / C::PW, px = pix - py * C::PW;
-    *reinterpret_cast<f32x4 *>(patch + py * C::ROWP + px * C::PS + q * 4) = v;
+    *reinterpret_cast<f32x4 *>(patch + C::lds_off(py, px, q)) = v;
 }
 
 __device__ __forceinline__ float apply_act(float v, int act)
@@ -272,6 +308,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
     float *const patch_buf = smem;                              // 2 x PATCH_FLOATS
 
     TL(0);
+    if (BSVD_TUNE_PRIO == 2) __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -303,7 +340,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
     const int ncb = p.Cin >> 4;
 
     // A fragments: per-lane offset into the LDS patch (floats)
-    const int a_lane = ((2 * C::MT * wm + (li >> 4)) * C::STRIDE) * C::ROWP + ((li & 15) * C::STRIDE) * C::PS + lh * 4;
+    const int a_lane = C::lds_off((2 * C::MT * wm + (li >> 4)) * C::STRIDE, (li & 15) * C::STRIDE, lh);
     // The weights are the MFMA's A operand (rows = output channels) and the pixels its B operand (columns), so a lane ends
     // up holding 16 output channels of ONE pixel: D row of register r is (r&3) + 8*(r>>2) + 4*lh.  Row i is fed with
     // channel chan(i) such that registers 0..7 / 8..15 of a lane are 8 consecutive channels each (groups 2h + lh):
@@ -321,13 +358,18 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    auto load_a = [&](const float *pc, int tap_off, f32x4 (&a)[C::MT][2]) {
-        const float *ap = pc + a_lane + tap_off;
+    // pixel fragments of tap (ky, KX): immediate offsets from the lane's base in both layouts
+    // (kx is a literal in the fast path's unrolled taps and folds into the instruction's offset field; the generic path passes
+    //  it at run time -- a three-way branch on kx there was miscompiled by hipcc 7.2: one arm lost an address register)
+    auto a_ptr = [&](const float *pc, int ky, int kx, int mt, int g) {
+        return pc + a_lane + ky * C::ROWP + (2 * mt * C::STRIDE) * C::ROWP + C::tap_off(kx, g);
+    };
+    auto load_a = [&](const float *pc, int ky, int kx, f32x4 (&a)[C::MT][2]) {
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
             for (int g = 0; g < 2; ++g)
-                a[mt][g] = *reinterpret_cast<const f32x4 *>(ap + (2 * mt * C::STRIDE) * C::ROWP + g * 8);
+                a[mt][g] = *reinterpret_cast<const f32x4 *>(a_ptr(pc, ky, kx, mt, g));
     };
     auto mfma32 = [&](const f32x4 (&a)[C::MT][2], const f32x4 (&b)[C::NT][2]) {
         if constexpr (PREC == 1) {
@@ -408,7 +450,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         const bool t_ok = r3 < C::R;
         const int gx = ix0 + pcol;
         const bool x_ok = t_ok && gx >= 0 && gx < p.W;
-        const int lds_item = r3 * C::ROWP + pcol * C::PS + pq * 4;            // floats, pass row 0
+        const int lds_item = C::lds_off(r3, pcol, pq);                        // floats, pass row 0
         auto slice_load = [&](const ChunkSrc &c, int row0, f32x4 (&v)[C::P]) {
 #pragma unroll
             for (int i = 0; i < C::P; ++i) {
@@ -492,7 +534,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
             in_patch = e < PNITEM;
             const bool ok = in_patch && gy >= 0 && gy < p.H && gxx >= 0 && gxx < p.W;
             voff = ok ? (unsigned)(gy * p.W + gxx) * ((unsigned)p.Cin * 4u) + pq4 * 16u : BSVD_OOB;
-            lds_off = prow * C::ROWP + pc * C::PS + pq4 * 4;
+            lds_off = C::lds_off(prow, pc, pq4);
         };
         auto fill_pair = [&](int cbe, float *pb) {      // stride-2 layers are plain convs: every chunk comes from the frame itself
             const unsigned so_e = (unsigned)cbe * 64u;
@@ -572,7 +614,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     if (g0 + j < PNI) {
                         const int e = tid + 256 * (g0 + j);
                         const int prow = e / C::ROW_ITEMS, rem2 = e - prow * C::ROW_ITEMS;
-                        if (e < PNITEM) *reinterpret_cast<f32x4 *>(pb + prow * C::ROWP + (rem2 >> 2) * C::PS + (rem2 & 3) * 4) = v[j];
+                        if (e < PNITEM) *reinterpret_cast<f32x4 *>(pb + C::lds_off(prow, rem2 >> 2, rem2 & 3)) = v[j];
                     }
             }
         };
@@ -583,6 +625,8 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         if constexpr (REGPF) prefetch_hold(1);
         __syncthreads();
         TL(1);
+        if (BSVD_TUNE_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+        if (BSVD_TUNE_PRIO == 3) __builtin_amdgcn_s_setprio(2);
 
         const int nsteps = ncb * 9;
         int step = 0;
@@ -598,13 +642,13 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         constexpr bool APF = PREC == 1 && C::DBUF && C::RING == 3 &&
                              (BSVD_TUNE_APF == 2 || (BSVD_TUNE_APF == 1 && C::NT == 1) || (BSVD_TUNE_APF == 3 && C::MT * C::NT >= 8));
         if constexpr (APF) {
-            auto load_hi = [&](const float *pc, int tap_off, f32x4 (&h)[C::MT]) {
+            auto load_hi = [&](const float *pc, int ky, int kx, f32x4 (&h)[C::MT]) {
 #pragma unroll
-                for (int mt = 0; mt < C::MT; ++mt) h[mt] = *reinterpret_cast<const f32x4 *>(pc + a_lane + tap_off + (2 * mt * C::STRIDE) * C::ROWP);
+                for (int mt = 0; mt < C::MT; ++mt) h[mt] = *reinterpret_cast<const f32x4 *>(a_ptr(pc, ky, kx, mt, 0));
             };
-            auto load_lo = [&](const float *pc, int tap_off, f32x4 (&l)[C::MT]) {
+            auto load_lo = [&](const float *pc, int ky, int kx, f32x4 (&l)[C::MT]) {
 #pragma unroll
-                for (int mt = 0; mt < C::MT; ++mt) l[mt] = *reinterpret_cast<const f32x4 *>(pc + a_lane + tap_off + (2 * mt * C::STRIDE) * C::ROWP + 8);
+                for (int mt = 0; mt < C::MT; ++mt) l[mt] = *reinterpret_cast<const f32x4 *>(a_ptr(pc, ky, kx, mt, 1));
             };
             auto pass = [&](const f32x4 (&av)[C::MT], const f32x4 (&bv)[C::NT][2], int bpart) {
 #pragma unroll
@@ -623,8 +667,8 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
 #pragma unroll
                 for (int i = 0; i < C::P; ++i) s1[i] = s2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 f32x4 hiA[C::MT], hiB[C::MT], loA[C::MT], loB[C::MT];
-                load_hi(pcur, 0, hiA);
-                load_lo(pcur, 0, loA);
+                load_hi(pcur, 0, 0, hiA);
+                load_lo(pcur, 0, 0, loA);
 #define BSVD_APF_TAP(T, HC, LC, HN, LN, BCUR, BFILL, SNEW, SOLD)                                                           \
                 {                                                                                                        \
                     load_b(step + 2 < nsteps ? step + 2 : nsteps - 1, BFILL);                                            \
@@ -633,8 +677,8 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     pass(LC, BCUR, 0);                                                      /* hi(w) x lo(x) */           \
                     __builtin_amdgcn_sched_barrier(0);                                                                   \
                     if constexpr ((T) < 8) {                                                                             \
-                        load_lo(pcur, (((T) + 1) / 3) * C::ROWP + (((T) + 1) % 3) * C::PS, LN);                          \
-                        load_hi(pcur, (((T) + 1) / 3) * C::ROWP + (((T) + 1) % 3) * C::PS, HN);                          \
+                        load_lo(pcur, ((T) + 1) / 3, ((T) + 1) % 3, LN);                                                 \
+                        load_hi(pcur, ((T) + 1) / 3, ((T) + 1) % 3, HN);                                                 \
                     }                                                                                                    \
                     __builtin_amdgcn_sched_barrier(0);                                      /* reads stay HERE: 16 MFMAs of cover */ \
                     pass(HC, BCUR, 1);                                                      /* lo(w) x hi(x) */           \
@@ -672,7 +716,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 {                                                                                              \
                     const int tap = ky * 3 + (KX);                                                             \
                     f32x4 a[C::MT][2];                                                                         \
-                    load_a(pcur, ky * C::ROWP + (KX) * C::PS, a);                                              \
+                    load_a(pcur, ky, (KX), a);                                                                 \
                     load_b(step + C::RING - 1 < nsteps ? step + C::RING - 1 : nsteps - 1, BFILL);              \
                     if constexpr (C::DBUF) slice_load(cn, tap * C::ROWS_PER_SLICE, SNEW);   /* rows >= PH: zeros */ \
                     mfma32(a, BCUR);                                                                           \
@@ -762,7 +806,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 }
                 const int ky = tap / 3, kx = tap - ky * 3;
                 f32x4 a[C::MT][2];
-                load_a(pcur, ky * C::ROWP + kx * C::PS, a);
+                load_a(pcur, ky, kx, a);
                 mfma32(a, bcur);
 #pragma unroll
                 for (int i = 0; i < C::QG; ++i) {
@@ -780,6 +824,8 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
     }
 
     TL(2);
+    if (BSVD_TUNE_PRIO == 1 || BSVD_TUNE_PRIO == 2) __builtin_amdgcn_s_setprio(2);
+    if (BSVD_TUNE_PRIO == 3) __builtin_amdgcn_s_setprio(0);
     // ---- epilogue.  Lane (li, lh) holds pixel li of the 2 x 16 pixel block of MFMA tile mt (row li>>4, column li&15)
     //      and, per (mt, nt), two groups of 8 consecutive output channels: registers 8h..8h+7 = channels 8*(2h + lh)..+7
     //      of the 32-channel tile.
@@ -1011,11 +1057,37 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     float *dst = t.dst;
                     constexpr bool bounded = ACT == BSVD_ACT_RELU6 && EPI == BSVD_EPI_PLAIN;
                     f16x8 hi, lo;
+                    // lo = fp16(v - hi).  MIXLO: ONE v_fma_mix{lo,hi}_f16 per element (fp16 operand widened inside the instruction,
+                    // exact fp32 difference, one rounding to fp16, written straight into its half of the packed register) instead
+                    // of v_cvt_f32_f16 + v_sub_f32 + half a v_cvt_pk_f16_f32: 12 instead of 20 conversion instructions per 8
+                    // channels, same bits (r03 digest check).  Measured r03, interleaved A/B: 64-channel tile 6.22 -> 6.18 ms per
+                    // clip, fat 128-accumulator tile 19.74 -> 19.87 (the asm statements pin the conversion in front of the
+                    // stores, which the compiler otherwise interleaves) -> on for the 64-accumulator tiles only.
+                    constexpr bool MIXLO = BSVD_TUNE_LO_BITS >= 10 && (BSVD_TUNE_MIXLO == 1 || (BSVD_TUNE_MIXLO == 2 && C::MT * C::NT < 8));
+                    if constexpr (MIXLO) {
+                        float vs[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {        // fp16 range guard: saturate instead of inf/NaN pairs
-                        const float vs = bounded ? v[j] : __builtin_amdgcn_fmed3f(v[j], -65504.f, 65504.f);
-                        hi[j] = (_Float16)vs;
-                        lo[j] = lo_keep((_Float16)__builtin_fmaf((float)hi[j], -1.0f, vs));
+                        for (int j = 0; j < 8; ++j) {        // fp16 range guard: saturate instead of inf/NaN pairs
+                            vs[j] = bounded ? v[j] : __builtin_amdgcn_fmed3f(v[j], -65504.f, 65504.f);
+                            hi[j] = (_Float16)vs[j];
+                        }
+                        const u32x4 hp = __builtin_bit_cast(u32x4, hi);
+                        u32x4 lp;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            unsigned l;
+                            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hp[k]), "v"(vs[2 * k]));
+                            asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hp[k]), "v"(vs[2 * k + 1]));
+                            lp[k] = l;
+                        }
+                        lo = __builtin_bit_cast(f16x8, lp);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {        // fp16 range guard: saturate instead of inf/NaN pairs
+                            const float vs = bounded ? v[j] : __builtin_amdgcn_fmed3f(v[j], -65504.f, 65504.f);
+                            hi[j] = (_Float16)vs;
+                            lo[j] = lo_keep((_Float16)__builtin_fmaf((float)hi[j], -1.0f, vs));
+                        }
                     }
 #if BSVD_TUNE_NT_STORE
                     __builtin_nontemporal_store(__builtin_bit_cast(f32x4, hi), reinterpret_cast<f32x4 *>(dst));
@@ -1129,6 +1201,7 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
         }
         if (stride == 2) {
             if (BSVD_TUNE_S2_SPLIT == 1) return launch_cfg<ConvCfg<1, 2, 2, 2, 2, 3, true>, true, 1>(p, stream, name, name_len);
+            if (BSVD_TUNE_S2_DBUF == 1) return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, true>, true, 1>(p, stream, name, name_len);
             return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, false>, true, 1>(p, stream, name, name_len);
         }
         // The fat tiles run one workgroup per CU, so they need a grid of several rounds of 256; small launches

@@ -177,6 +177,11 @@ class StreamEngine:
         self._lag = None
 
     def release(self):
+        """Frees graphs and rings.  Replays may still be in flight on whatever streams the caller used (LiveStream's compute
+        stream, the capture / side streams): the device is drained first, so neither a graph is destroyed under a running
+        replay nor a ring block handed back to the caching allocator while a kernel on another stream still uses it."""
+        if self.hip:
+            torch.cuda.synchronize(self.ex.device)
         for g, _ in self.graphs.values():
             if g is not None:
                 self.ex.lib.bsvd_graph_destroy(g)

@@ -63,3 +63,24 @@ def test_two_process_sharding_on_one_gpu(tmp_path, precision):
     whole = np.load(tmp_path / "whole.npy")
     assert y.shape == whole.shape == (7, 3, 32, 48)
     assert np.array_equal(y, whole), "sharded == unsharded bit for bit (max diff %g)" % np.abs(y - whole).max()
+
+
+def test_rccl_loopback_world_size_1_drives_the_device_buffer_halo_path():
+    """the RCCL point-to-point branch of HaloExchanger on real RCCL with a loopback neighbour
+    (tests/rccl_loopback_driver.py): req.wait() stream ordering, pinning of the packed send slices, receive-buffer
+    lifetime under the caching allocator.  If this RCCL build refuses self send/recv the exact error is shown and the test
+    is skipped (then only an N > 1 run can exercise the branch)."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(HERE, "rccl_loopback_driver.py"), str(_free_port())],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stderr[-2000:])
+    res = json.loads(lines[-1][len("RESULT "):])
+    print("\n[rccl loopback] %s" % json.dumps(res))
+    if "error" in res:
+        pytest.skip("RCCL loopback not possible here: %s" % res["error"])
+    assert res["group_backend"] == "nccl"
+    for precision, o in res["loopback"].items():
+        assert o["equal"], (precision, o)
+        assert o["exchanges"] == 3 * 16 and o["bytes_sent"] > 0

@@ -195,3 +195,43 @@ def test_blind_c64_at_set8_geometry_vs_oracle_and_schedules(precision):
         m.stream_chunk = chunk
         assert torch.equal(m.streaming_forward(xs), y)
     m.release_stream_buffers()
+
+
+def test_headline_clip_c1_whole_clip_vs_cpu_oracle_both_precisions(capsys):
+    """BASELINE config C1 -- the clip bench.py's headline number is quoted on, [1,10,4,540,960] sigma=30 -- WHOLE, against the
+    CPU oracle (the reference's algorithm on torch conv2d fp32, pinned to the reference goldens), in both arithmetic modes.
+    north_star budget: 1e-3 max-abs.  About 15 s of host time on the box's 16 usable cores; the number is printed so that it
+    shows in the driver's GPU-test log."""
+    import os
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from oracle import bsvd_oracle as O
+    torch.set_num_threads(bench.usable_cores())
+    g = torch.Generator().manual_seed(20260928)
+    clean = torch.nn.functional.avg_pool2d(torch.rand((10, 3, 540, 960), generator=g), 5, 1, 2)[None]
+    lq = clean + torch.randn(clean.shape, generator=g) * (30.0 / 255.0)
+    nm = torch.full((1, 10, 1, 540, 960), 30.0 / 255.0)
+    st = seeded_state(bsvd_keys([64, 128, 256], 64, 4, 3, 64), 11)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        want = O.bsvd_clip(lq, O.to_torch_state(st), noise_map=nm)[0]
+    t_cpu = time.perf_counter() - t0
+    x = torch.cat([lq, nm], dim=2).to(_dev())
+    report = {}
+    for precision in PRECISIONS:
+        m = _model(precision, mode="auto")
+        y = m(x)[0]
+        torch.cuda.synchronize()
+        assert m.last_mode == "clip"
+        err = float((y.cpu() - want).abs().max())
+        report[precision] = err
+        assert tuple(y.shape) == (10, 3, 540, 960)
+        assert err < 1e-3, (precision, err)
+        assert err < (3e-4 if precision == "f16x3" else 1.5e-4), (precision, err)      # regression guard, well inside the budget
+        del m, y
+    with capsys.disabled():
+        print("\n[C1 whole-clip parity] [1,10,4,540,960] vs CPU oracle (%.1f s on %d threads, |out|max %.2f): "
+              "max-abs f16x3 %.3e, exact fp32 %.3e (budget 1e-3)"
+              % (t_cpu, torch.get_num_threads(), float(want.abs().max()), report["f16x3"], report["fp32"]))

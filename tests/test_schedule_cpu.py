@@ -252,3 +252,35 @@ def test_precision_auto_picks_split_when_the_network_admits_it():
     assert odd.precision == "fp32" and odd.precision_requested == "auto"                # fold 4 / 8 on 32 / 64 channels... not admitted
     with pytest.raises(ValueError):
         bsvd_amd.BSVD(chns=[16, 32, 64], mid_ch=16, norm="none", interm_ch=16, pretrain_ckpt=None, precision="f16x3")
+
+
+def test_parameter_swap_invalidates_the_cached_signature_and_bn_eps_is_read_from_the_module():
+    """the engine caches its parameter list; replacing a Parameter OBJECT (module.weight = nn.Parameter(...)),
+    a buffer or a sub-module must still be noticed -> the cache is keyed by torch's global registration hooks.  And the
+    BatchNorm fold takes each module's own eps."""
+    import bsvd_amd
+    import torch.nn as nn
+    m = bsvd_amd.BSVD(chns=[16, 32, 64], mid_ch=16, interm_ch=16, norm="bn", act="relu", pretrain_ckpt=None,
+                      engine_mode="clip", precision="fp32").eval()
+    s0 = m._signature()
+    assert m._signature() == s0
+    conv = m.temp1.inc.convblock["0"]
+    conv.weight = nn.Parameter(conv.weight.detach().clone() * 2)          # a NEW Parameter object
+    s1 = m._signature()
+    assert s1 != s0
+    bn = m.temp1.inc.convblock["1"]
+    bn.register_buffer("running_var", bn.running_var.clone() + 1.0)         # a NEW buffer object
+    s2 = m._signature()
+    assert s2 != s1
+    m.temp2.outc.convblock["0"] = nn.Conv2d(16, 16, 3, padding=1)           # a swapped sub-module
+    assert m._signature() != s2
+    # per-module eps reaches the fold
+    bn.eps = 0.5
+    st = m._engine_state()
+    w_raw = m.state_dict()["temp1.inc.convblock.0.weight"]
+    scale = bn.weight.detach() / torch.sqrt(bn.running_var + 0.5)
+    assert torch.allclose(st["temp1.inc.convblock.0.weight"], w_raw * scale[:, None, None, None], rtol=1e-6, atol=1e-7)
+    t = bsvd_amd.TSN(net2d_opt=dict(chns=[16, 32, 64], mid_ch=16, interm_ch=16, norm="bn", act="relu")).eval()
+    names = dict(t._bsvd_modules())
+    assert "temp1.inc.convblock.1" in names and "temp2.upc1.memconv.b2" in names
+    assert set(t._engine_state()) == set(st)
