@@ -522,10 +522,18 @@ class BSVD(_HipNet):
         N, F, C, H, W = input.shape
         frames = input.reshape(N * F, C, H, W)
         self.last_mode = self._pick_mode(N * F, H, W)
+        if self.last_mode == "clip":
+            try:
+                out = self.clip_forward(frames)
+            except torch.cuda.OutOfMemoryError:
+                if self.engine_mode != "auto":
+                    raise
+                # the (cached) decision met a device that has less room now: same function, O(1)-memory schedule
+                self.__dict__.pop("_mode_cache", None)
+                torch.cuda.empty_cache()
+                self.last_mode = "stream"
         if self.last_mode == "stream":
             out = self.streaming_forward(frames)
-        else:
-            out = self.clip_forward(frames)
         return out.reshape(N, F, out.shape[1], H, W)
 
     def _pick_mode(self, frames, H, W):

@@ -34,6 +34,13 @@ __device__ __forceinline__ float edge_act(float v, int act)
 }
 
 // ------------------------------------------------------------------------------------------------------
+// (r03: a two-pixels-per-thread version on v_pk_fma_f32 with the weights broadcast from LDS ran 0.53 ms instead of 0.62 ms per
+//  10-frame 540x960 clip and is bit-identical when it runs alone -- but while a split-fp16 MFMA kernel of ANOTHER stream shares the
+//  SIMDs (the two-branch graphs of streaming_forward) single accumulators came out wrong in the last 16 lanes of a wave in 30-100 %
+//  of the runs (tools/debug/head_stress.py; never with an fp32-MFMA or a copy kernel alongside, never alone).  Ruled out:
+//  inline-asm hazards (compiler-generated v_pk_fma_f32 behaves the same), the store-data / LDS-return register reuse of the
+//  write-back, the refill distance of the weight registers, LDS corruption by the neighbour kernel (canary workgroups stay
+//  intact).  Not understood -> not shipped; this one-pixel kernel is deterministic under the same stress.)
 // head: thread = one pixel; workgroup = 64 x 4 pixels (a wave reads 64 consecutive x of one row: coalesced planes)
 template <int CIN>
 __global__ __launch_bounds__(256) void head_kernel(const ConvParams p)

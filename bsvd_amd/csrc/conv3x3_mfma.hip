@@ -57,15 +57,16 @@
 #define BSVD_TUNE_APF 1        // split DBUF tiles that request the NEXT tap's pixel fragments in the middle of the current tap: 0 none, 1 the exit tile (NT == 1), 2 all, 3 fat tiles
 #endif
 #ifndef BSVD_TUNE_QPL
-#define BSVD_TUNE_QPL 3        // quad-planar LDS patch ([row][16-B channel quad][column], row pitch a multiple of 256 B): bit 0 the 256-px tiles
-                               // (64-channel layers, exit layer), bit 1 the stride-2 tile (even / odd columns in separate planes), bit 2 the
-                               // 128-channel stride-1 tiles (which already read conflict-free from the padded 80-B layout at a 1536-B pitch)
+#define BSVD_TUNE_QPL 5        // quad-planar LDS patch ([row][16-B channel quad][column], row pitch a multiple of 256 B), per tile family:
+                               //   bit 0  the 256-px x 64-ch tile <2,2,4,1,1> and the exit tile <2,1,4,1,1>   (r03: bank conflicts 0.46 / 0.49 -> 0.06 / 0.00
+                               //          of the LDS cycles, 6.25 -> 6.22 ms per clip: the conflicts were not what these tiles wait for)
+                               //   bit 1  the stride-2 tile (even / odd columns in separate planes): conflicts 0.44 -> 0.15, but 2.29 -> 2.34 ms: off
+                               //   bit 2  the 128-px x 32-ch wave tile <4,1,2,2,1> of the 64-channel layers (8 pixel-fragment reads per 12 MFMAs:
+                               //          this one needs conflict-free reads -- 6.42 -> 5.94 ms per clip against <2,2,4,1,1>, r03)
+                               //   bit 3  the 128-channel stride-1 tiles (already conflict-free in the padded layout at a 1536-B pitch): 20.55 -> 20.70 ms: off
 #endif
 #ifndef BSVD_TUNE_PRIO
 #define BSVD_TUNE_PRIO 0       // s_setprio experiment: 1 = epilogue at priority 2, 2 = prologue + epilogue at priority 2, 3 = K loop at priority 2
-#endif
-#ifndef BSVD_TUNE_MIXLO
-#define BSVD_TUNE_MIXLO 2      // split epilogue: lo halves by v_fma_mix{lo,hi}_f16: 0 never (cvt + sub + cvt_pk), 1 always, 2 the 64-accumulator tiles
 #endif
 #ifndef BSVD_TUNE_S2_DBUF
 #define BSVD_TUNE_S2_DBUF 0    // 1: split-fp16 stride-2 tile with a double-buffered (swizzled) patch at 2 workgroups per CU
@@ -116,7 +117,8 @@ struct ConvCfg {
     // apart modulo the 128-B write bank row.  64 B per pixel instead of 80: 4/5 of the padded layout's LDS.  Stride 2: a tap
     // reads every other column, so even and odd columns get separate planes ([row][quad][parity][column / 2]).
     static constexpr bool QPL = (STRIDE == 2) ? (BSVD_TUNE_QPL & 2) != 0
-                                              : ((MT == 2 && WM == 4) ? (BSVD_TUNE_QPL & 1) != 0 : (BSVD_TUNE_QPL & 4) != 0);
+                                : (MT == 2 && WM == 4) ? (BSVD_TUNE_QPL & 1) != 0
+                                : (NT == 1)            ? (BSVD_TUNE_QPL & 4) != 0 : (BSVD_TUNE_QPL & 8) != 0;
     static constexpr int PS = QPL ? 16 : 20;           // floats per patch pixel
     static constexpr int PLANE = STRIDE == 2 ? ((PW + 1) / 2) * 4 : PW * 4;      // QPL: floats per (quad[, parity]) plane of a row
     static constexpr int NP = PH * PW;                 // patch pixels
@@ -1057,37 +1059,14 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     float *dst = t.dst;
                     constexpr bool bounded = ACT == BSVD_ACT_RELU6 && EPI == BSVD_EPI_PLAIN;
                     f16x8 hi, lo;
-                    // lo = fp16(v - hi).  MIXLO: ONE v_fma_mix{lo,hi}_f16 per element (fp16 operand widened inside the instruction,
-                    // exact fp32 difference, one rounding to fp16, written straight into its half of the packed register) instead
-                    // of v_cvt_f32_f16 + v_sub_f32 + half a v_cvt_pk_f16_f32: 12 instead of 20 conversion instructions per 8
-                    // channels, same bits (r03 digest check).  Measured r03, interleaved A/B: 64-channel tile 6.22 -> 6.18 ms per
-                    // clip, fat 128-accumulator tile 19.74 -> 19.87 (the asm statements pin the conversion in front of the
-                    // stores, which the compiler otherwise interleaves) -> on for the 64-accumulator tiles only.
-                    constexpr bool MIXLO = BSVD_TUNE_LO_BITS >= 10 && (BSVD_TUNE_MIXLO == 1 || (BSVD_TUNE_MIXLO == 2 && C::MT * C::NT < 8));
-                    if constexpr (MIXLO) {
-                        float vs[8];
+                    // (lo = fp16(v - hi) as inline-asm v_fma_mix{lo,hi}_f16 was tried in r03: 12 instead of 20 conversion instructions
+                    //  per 8 channels, bit-identical, 64-channel tile 6.22 -> 6.18 ms per clip but the fat tile 19.74 -> 19.87 -- and an
+                    //  inline-asm partial-register write is invisible to the compiler's hazard recognizer, so it was dropped.)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {        // fp16 range guard: saturate instead of inf/NaN pairs
-                            vs[j] = bounded ? v[j] : __builtin_amdgcn_fmed3f(v[j], -65504.f, 65504.f);
-                            hi[j] = (_Float16)vs[j];
-                        }
-                        const u32x4 hp = __builtin_bit_cast(u32x4, hi);
-                        u32x4 lp;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            unsigned l;
-                            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hp[k]), "v"(vs[2 * k]));
-                            asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hp[k]), "v"(vs[2 * k + 1]));
-                            lp[k] = l;
-                        }
-                        lo = __builtin_bit_cast(f16x8, lp);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {        // fp16 range guard: saturate instead of inf/NaN pairs
-                            const float vs = bounded ? v[j] : __builtin_amdgcn_fmed3f(v[j], -65504.f, 65504.f);
-                            hi[j] = (_Float16)vs;
-                            lo[j] = lo_keep((_Float16)__builtin_fmaf((float)hi[j], -1.0f, vs));
-                        }
+                    for (int j = 0; j < 8; ++j) {        // fp16 range guard: saturate instead of inf/NaN pairs
+                        const float vs = bounded ? v[j] : __builtin_amdgcn_fmed3f(v[j], -65504.f, 65504.f);
+                        hi[j] = (_Float16)vs;
+                        lo[j] = lo_keep((_Float16)__builtin_fmaf((float)hi[j], -1.0f, vs));
                     }
 #if BSVD_TUNE_NT_STORE
                     __builtin_nontemporal_store(__builtin_bit_cast(f32x4, hi), reinterpret_cast<f32x4 *>(dst));
@@ -1213,7 +1192,10 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
                                     : launch_cfg<ConvCfg<2, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
         if (p.fold == 8) return launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1, true>(p, stream, name, name_len);   // c32-sized nets
 #ifndef BSVD_TUNE_NARROW_ALT
-#define BSVD_TUNE_NARROW_ALT 0     // 1: 128-px x 32-ch wave tiles (<4,1,2,2>) for the 64-channel layers instead of 64 x 64
+#define BSVD_TUNE_NARROW_ALT 1     // 1: 128-px x 32-ch wave tiles (<4,1,2,2,1>, 2 waves per SIMD) for the 64-channel layers instead of 64 px x 64 ch at 3 waves
+                                   // per SIMD: half the weight bytes per MFMA (the 64 x 64 tile pulled 4 KB of weights per wave and tap through the
+                                   // L1: ~42 B/clk/CU of its 64), twice the pixel-fragment reads -- a loss with the padded LDS layout (r01: "no gain"),
+                                   // a 7 % gain with the conflict-free quad-planar one (r03: 6.42 -> 5.94 ms per clip on one box)
 #endif
         if (BSVD_TUNE_NARROW_ALT) return launch_cfg<ConvCfg<4, 1, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
         return launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1>(p, stream, name, name_len);   // (512-px fat tiles were tried: 9.6 vs 6.8 ms)

@@ -162,8 +162,28 @@ def test_auto_mode_falls_back_to_stream_when_the_clip_does_not_fit(monkeypatch):
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a, **k: (1 << 30, 288 << 30))
     monkeypatch.setattr(torch.cuda, "memory_reserved", lambda *a, **k: 0)
     monkeypatch.setattr(torch.cuda, "memory_allocated", lambda *a, **k: 0)
+    # the decision is cached per clip geometry (no memory query per call) ...
+    assert m(x[None])[0].shape == y.shape and m.last_mode == "clip"
+    # ... a cached 'clip' that meets a fuller device falls back on the allocator's OutOfMemoryError ...
+    real_clip, calls = m.clip_forward, []
+
+    def oom_once(frames, halo_fn=None):
+        calls.append(1)
+        raise torch.cuda.OutOfMemoryError("simulated")
+
+    m.clip_forward = oom_once
+    y3 = m(x[None])[0]
+    m.clip_forward = real_clip
+    assert calls and m.last_mode == "stream" and torch.equal(y3, y)
+    # ... and the next decision is taken afresh.  The rings the stream schedule left behind count as reusable: with "1 GiB
+    # free" + 9 GB of own rings the clip fits again once they are handed back
+    assert m._stream_engs
+    y4 = m(x[None])[0]
+    assert m.last_mode == "clip" and not m._stream_engs and torch.equal(y4, y) and len(calls) == 1
+    # nothing to hand back and 1 GiB free: the stream schedule from the start
+    m.__dict__.pop("_mode_cache", None)
     y2 = m(x[None])[0]
-    assert m.last_mode == "stream" and torch.equal(y2, y)
+    assert m.last_mode == "stream" and torch.equal(y2, y) and len(calls) == 1
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
