@@ -53,6 +53,9 @@
 #ifndef BSVD_TUNE_FAT_OCC
 #define BSVD_TUNE_FAT_OCC 2        // waves/SIMD the 128-accumulator tiles are compiled for
 #endif
+#ifndef BSVD_TUNE_NARROW_OCC
+#define BSVD_TUNE_NARROW_OCC 3     // waves/SIMD the 128-px x 32-ch wave tile is compiled for (3: 168 VGPRs + a 12-byte spill; 2: no spill)
+#endif
 #ifndef BSVD_TUNE_APF
 #define BSVD_TUNE_APF 1        // split DBUF tiles that request the NEXT tap's pixel fragments in the middle of the current tap: 0 none, 1 the exit tile (NT == 1), 2 all, 3 fat tiles
 #endif
@@ -154,7 +157,7 @@ struct ConvCfg {
     static_assert(NSLICE <= 7, "slices are loaded at taps 0..6 and stored two taps later (2..8)");
     // workgroups per CU the LDS footprint admits (160 KiB) -> register budget for __launch_bounds__
     static constexpr int OCC_LDS = LDS_BYTES > 80 * 1024 ? 1 : (LDS_BYTES > 53 * 1024 ? 2 : 3);
-    static constexpr int OCC = (MT * NT >= 8) ? BSVD_TUNE_FAT_OCC : OCC_LDS;   // 128 accumulator registers (AGPRs) + <= 128 VGPRs: two waves per SIMD
+    static constexpr int OCC = (MT * NT >= 8) ? BSVD_TUNE_FAT_OCC : (MT == 4 && NT == 1 && OCC_LDS > BSVD_TUNE_NARROW_OCC) ? BSVD_TUNE_NARROW_OCC : OCC_LDS;   // 128 accumulator registers (AGPRs) + <= 128 VGPRs: two waves per SIMD
 };
 
 struct SrcSel {            // per-frame sources of the temporal-shift gather (wave uniform)
@@ -1187,9 +1190,14 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
         // (streaming mode: one frame per launch) keep the 64x64 tiles at 3 workgroups per CU.
         const int64_t fat_wide = (int64_t)p.frames * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16) * ((p.Cout + 127) / 128);
         static const int fat_min = [] { const char *e = getenv("BSVD_FAT_MIN_WGS"); return e ? atoi(e) : BSVD_TUNE_FAT_MIN_WGS; }();   // tuning override
-        if (p.Cout > 64)
-            return fat_wide >= fat_min ? launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len)
-                                    : launch_cfg<ConvCfg<2, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
+#ifndef BSVD_TUNE_THIN_ALT
+#define BSVD_TUNE_THIN_ALT 0       // 1: small grids of the wide layers (single-frame launches) on <4,1,2,2,1> (256 px x 64 ch workgroups, two channel tiles)
+#endif
+        if (p.Cout > 64) {
+            if (fat_wide >= fat_min) return launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
+            if (BSVD_TUNE_THIN_ALT) return launch_cfg<ConvCfg<4, 1, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
+            return launch_cfg<ConvCfg<2, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
+        }
         if (p.fold == 8) return launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1, true>(p, stream, name, name_len);   // c32-sized nets
 #ifndef BSVD_TUNE_NARROW_ALT
 #define BSVD_TUNE_NARROW_ALT 1     // 1: 128-px x 32-ch wave tiles (<4,1,2,2,1>, 2 waves per SIMD) for the 64-channel layers instead of 64 px x 64 ch at 3 waves
