@@ -78,6 +78,16 @@ def build_model(device, precision="fp32", blind=False):
     return m.to(device).eval()
 
 
+class _Both:
+    """FLOP accounting of a fused pair of layers"""
+
+    def __init__(self, *sps):
+        self.sps = sps
+
+    def macs(self, h, w):
+        return sum(sp.macs(h, w) for sp in self.sps)
+
+
 class LaunchTimer:
     """Wraps HipExecutor.conv with a HIP event pair per launch (same stream as the kernel).  Events come from a pool
     that is filled during the warmup steps and re-recorded in the timed region, and the kernel-variant names are cached
@@ -90,6 +100,8 @@ class LaunchTimer:
         self.names = {}
         self._orig = ex.conv
         ex.conv = self._conv
+        self._orig_fused = ex.conv_head_fused
+        ex.conv_head_fused = self._fused
 
     def _event(self):
         if self.used == len(self.pool):
@@ -114,6 +126,21 @@ class LaunchTimer:
         self.records.append((sp, T, Hh, Ww, e0, e1, name))
         return y
 
+    def _fused(self, sp0, sp3, x, *a, **k):
+        """InputCvBlock as one launch (engine.head_fusable): its algorithmic FLOP are the two convs'"""
+        key = (sp3.key, tuple(x.shape), "fused")
+        name = self.names.get(key)
+        self.ex.record_variants = name is None
+        e0, e1 = self._event(), self._event()
+        e0.record()
+        y = self._orig_fused(sp0, sp3, x, *a, **k)
+        e1.record()
+        if name is None:
+            name = self.names[key] = self.ex.last_variant
+        T, _, Hh, Ww = x.shape
+        self.records.append((_Both(sp0, sp3), T, Hh, Ww, e0, e1, name))
+        return y
+
     def reserve(self, steps):
         """grow the pool to `steps` x (events used since the last reset), creating the HIP events now (record() creates)"""
         need = steps * max(self.used, 1)
@@ -128,6 +155,7 @@ class LaunchTimer:
 
     def detach(self):
         self.ex.conv = self._orig
+        self.ex.conv_head_fused = self._orig_fused
         self.ex.record_variants = False
 
     def summary(self):

@@ -198,6 +198,29 @@ __global__ void planar_to_u8_kernel(const float *__restrict__ src, uint8_t *__re
     }
 }
 
+// weights of the fused network entry: one thread per (pair, k-step, lane, j): A operand of v_mfma_f32_32x32x16_f16, rows = the
+// channel permutation `chan` of conv3x3_kernel (a lane ends with two groups of 8 consecutive channels)
+__global__ void pack_head_weights_kernel(const float *__restrict__ w, const float *__restrict__ bias, int Cin, int Cmid, int Cmid_pad,
+                                         _Float16 *__restrict__ wp, float *__restrict__ bp)
+{
+    const int total = (Cmid_pad / 32) * 3 * 64 * 8;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i & 7, lane = (i >> 3) & 63, ps = i >> 9, sidx = ps % 3, pair = ps / 3;
+        const int row = lane & 31, kb = lane >> 5;
+        const int rrow = (row & 3) + 4 * (row >> 3);
+        const int ch = pair * 32 + 8 * (2 * (rrow >> 3) + ((row >> 2) & 1)) + (rrow & 7);
+        const int k = 16 * sidx + 8 * kb + j, tap = k >> 2, c = k & 3;
+        float v = 0.f;
+        if (ch < Cmid && tap < 9 && c < Cin) v = w[((int64_t)ch * Cin + c) * 9 + tap];
+        const _Float16 hi = (_Float16)v;
+        _Float16 *dst = wp + ((int64_t)(ps * 64 + lane)) * 16;
+        dst[j] = hi;
+        dst[8 + j] = lo_keep((_Float16)(v - (float)hi));
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Cmid_pad; i += gridDim.x * blockDim.x)
+        bp[i] = (bias && i < Cmid) ? bias[i] : 0.f;
+}
+
 static inline unsigned grid_for(int64_t n, int block)
 {
     int64_t g = (n + block - 1) / block;
@@ -270,6 +293,7 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
     p.prec = a->dtype == BSVD_F16X3 ? 1 : 0;
     p.extra_split = a->extra_split;
     p.y_planar_ch = a->y_planar_ch; p.y_clamp = a->y_clamp; p.y_lo = a->y_lo; p.y_hi = a->y_hi;
+    p.head_w = nullptr; p.head_bias = nullptr; p.head_cin = 0;
 #ifdef BSVD_ABLATE
     if (const char *e = getenv("BSVD_ABLATE")) p.ablate = atoi(e);
 #endif
@@ -278,6 +302,19 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
         if (a->x_planar_ch > 0 && a->y_planar_ch > 0) { set_error("bsvd_conv3x3: x_planar_ch and y_planar_ch are exclusive"); return -16; }
         if (a->stride != 1 || a->fold != 0) { set_error("bsvd_conv3x3: planar edge layers need stride 1 and fold 0"); return -16; }
         if ((int64_t)a->H * a->W * (a->Cin > a->Cout ? a->Cin : a->Cout) >= 0x7fffffffLL) { set_error("bsvd_conv3x3: frame too large for the edge kernels"); return -16; }
+        if (a->x_planar_ch > 0 && a->head_w_packed) {
+            // fused network entry: planar input -> (x_planar_ch -> Cin conv, act) -> (Cin -> Cout conv, act), one launch
+            if (a->dtype != BSVD_F16X3) { set_error("bsvd_conv3x3: the fused entry (head_w_packed) is a BSVD_F16X3 kernel"); return -18; }
+            if (a->x_planar_ch != 3 && a->x_planar_ch != 4) { set_error("bsvd_conv3x3: fused entry supports 3 or 4 planar input channels, got %d", a->x_planar_ch); return -18; }
+            if ((a->Cin & 31) || a->Cout > 64 || a->epilogue != BSVD_EPI_PLAIN || a->y_planar_ch > 0) {
+                set_error("bsvd_conv3x3: fused entry needs Cin %% 32 == 0, Cout <= 64 and the PLAIN epilogue (Cin %d, Cout %d)", a->Cin, a->Cout); return -18;
+            }
+            if (!a->head_bias || (((uintptr_t)a->head_w_packed) & 15) || (((uintptr_t)a->head_bias) & 15)) { set_error("bsvd_conv3x3: fused entry needs 16-byte aligned head_w_packed and head_bias"); return -18; }
+            if ((int64_t)a->H * a->W * a->Cout * 4 >= 0x7fffffffLL) { set_error("bsvd_conv3x3: frame too large for the fused entry"); return -18; }
+            p.head_w = a->head_w_packed; p.head_bias = (const float *)a->head_bias; p.head_cin = a->x_planar_ch;
+            p.vec_ok = 1;
+            return launch_conv3x3(p, 1, (hipStream_t)stream, name, name_len);
+        }
         if (a->x_planar_ch > 0) {
             if (a->Cin != 16 || a->epilogue != BSVD_EPI_PLAIN) { set_error("bsvd_conv3x3: planar input needs Cin == 16 (padded) and the PLAIN epilogue"); return -16; }
             if (name) { snprintf(name, name_len, "head_kernel<%d>%s", a->x_planar_ch, p.prec == 1 ? "[f16x3 out]" : "[f32]"); return 0; }
@@ -323,6 +360,20 @@ int bsvd_pack_weights(const float *w, const float *bias, int32_t Cin, int32_t Co
     }
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, w, bias, Cin,
                        Cout, Cin_pad, Cout_pad, pixel_shuffle ? 1 : 0, (float *)wp, (float *)bp);
+    return (int)hipGetLastError();
+}
+
+int64_t bsvd_packed_head_weight_bytes(int32_t Cmid_pad) { return (int64_t)(Cmid_pad / 32) * 3 * 64 * 32; }
+
+int bsvd_pack_head_weights(const float *w, const float *bias, int32_t Cin, int32_t Cmid, int32_t Cmid_pad, void *wp, float *bp,
+                           void *stream)
+{
+    if (!w || !wp || !bp) { set_error("bsvd_pack_head_weights: NULL pointer"); return -3; }
+    if ((Cin != 3 && Cin != 4) || Cmid <= 0 || Cmid_pad < Cmid || (Cmid_pad & 31)) {
+        set_error("bsvd_pack_head_weights: needs Cin 3|4 and Cmid_pad %% 32 == 0 (Cin %d, Cmid %d -> %d)", Cin, Cmid, Cmid_pad); return -5;
+    }
+    hipLaunchKernelGGL(pack_head_weights_kernel, dim3(grid_for((int64_t)(Cmid_pad / 32) * 3 * 64 * 8, 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, bias, Cin, Cmid, Cmid_pad, (_Float16 *)wp, bp);
     return (int)hipGetLastError();
 }
 

@@ -30,6 +30,10 @@ struct ConvParams {
     int32_t y_planar_ch;     // > 0: y is planar [frames][y_planar_ch][H][W] fp32 (split mode: written by the MFMA kernel)
     int32_t y_clamp;         // clamp the planar output to [y_lo, y_hi]
     float y_lo, y_hi;
+    // fused network entry (BsvdConvArgs.head_w_packed): x is the planar fp32 input with head_cin channels
+    const void *head_w;
+    const float *head_bias;
+    int32_t head_cin;
 };
 
 void set_error(const char *fmt, ...);

@@ -306,7 +306,11 @@ __device__ __forceinline__ void tl_stamp(int slot, int k)
 #else
 #define TL(k)
 #endif
-template <class C, bool FAST, int PREC, bool MIXF = false>
+// HEADF (fused network entry, BsvdConvArgs.head_w_packed): p.x is the caller's planar fp32 input; the tile computes the
+// first conv's output (head_cin -> Cin channels, act, zero outside the image) on its own 18 x 18 patch with MFMAs
+// (K = 9 taps x 4 channels, padded to 48) straight into the LDS patch buffers, a pair of 16-channel chunks at a time, and
+// never reads an NHWC input tensor.  See head_pair below.
+template <class C, bool FAST, int PREC, bool MIXF = false, bool HEADF = false>
 __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -623,7 +627,83 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     }
             }
         };
-        if constexpr (PAIRPF) { prefetch_pair(0); publish_even(patch_buf); }
+        // ---- fused network entry: the raw input patch (TH+4) x (TW+4) x head_cin, split to fp16 pairs, 16 B per pixel
+        //      [hi c0..3 | lo c0..3], behind the two patch buffers; the first conv's output is then computed per chunk pair
+        constexpr int RPH = C::TH + 4, RPW = C::TW + 4;
+        [[maybe_unused]] unsigned char *const rawp = reinterpret_cast<unsigned char *>(smem) + C::LDS_BYTES;
+        [[maybe_unused]] auto head_pair = [&](int pair) {
+            static_assert(!HEADF || (C::QPL && C::STRIDE == 1 && C::DBUF && PREC == 1), "fused entry: quad-planar stride-1 split tile");
+            constexpr int NPIX = C::PH * C::PW, NRT = (NPIX + 31) / 32;
+            const float *hb = p.head_bias + pair * 32 + 8 * lh;      // this lane's two groups of 8 channels: +0 (chunk 2*pair), +16 (chunk 2*pair+1)
+            const f32x4 bia[2][2] = {{*reinterpret_cast<const f32x4 *>(hb), *reinterpret_cast<const f32x4 *>(hb + 4)},
+                                     {*reinterpret_cast<const f32x4 *>(hb + 16), *reinterpret_cast<const f32x4 *>(hb + 20)}};
+            const f32x4 *wbase = reinterpret_cast<const f32x4 *>(p.head_w) + ((int64_t)pair * 3 * 64 + lane) * 2;
+            const float vlo = p.act >= BSVD_ACT_RELU ? 0.f : -65504.f, vhi = p.act == BSVD_ACT_RELU6 ? 6.f : 65504.f;
+            for (int rt = wid; rt < NRT; rt += 4) {                 // 32-pixel row tiles of the patch, dealt to the 4 waves
+                const int m = rt * 32 + li;
+                const int mm = m < NPIX ? m : NPIX - 1;
+                const int py = mm / C::PW, px = mm - py * C::PW;
+                const unsigned char *rp = rawp + (py * RPW + px) * 16;
+                f32x16 hacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+#pragma unroll
+                for (int sidx = 0; sidx < 3; ++sidx) {
+                    // this lane's 8 k-slots of the step: taps ta, ta + 1 (4 channels each); taps >= 9 carry zero weights
+                    int ta = 4 * sidx + 2 * lh, tb = ta + 1;
+                    ta = ta < 9 ? ta : 0; tb = tb < 9 ? tb : 0;
+                    const int ya = ta / 3, yb = tb / 3;
+                    const u32x4 r1 = *reinterpret_cast<const u32x4 *>(rp + (ya * RPW + (ta - 3 * ya)) * 16);
+                    const u32x4 r2 = *reinterpret_cast<const u32x4 *>(rp + (yb * RPW + (tb - 3 * yb)) * 16);
+                    const f16x8 xh = __builtin_bit_cast(f16x8, u32x4{r1[0], r1[1], r2[0], r2[1]});
+                    const f16x8 xl = __builtin_bit_cast(f16x8, u32x4{r1[2], r1[3], r2[2], r2[3]});
+                    const f16x8 wh = __builtin_bit_cast(f16x8, wbase[sidx * 128]), wl = __builtin_bit_cast(f16x8, wbase[sidx * 128 + 1]);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, hacc, 0, 0, 0);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, hacc, 0, 0, 0);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, hacc, 0, 0, 0);
+                }
+                const int gy = iy0 + py, gx = ix0 + px;
+                const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;      // outside the image: the main conv's zero padding
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {                      // h: chunk 2*pair + h = patch buffer h
+                    f16x8 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float v = hacc[8 * h + j] + bia[h][j >> 2][j & 3];
+                        v = inside ? __builtin_amdgcn_fmed3f(v, vlo, vhi) : 0.f;
+                        hi[j] = (_Float16)v;
+                        lo[j] = lo_keep((_Float16)(v - (float)hi[j]));
+                    }
+                    float *dst = patch_buf + h * C::PATCH_FLOATS + C::lds_off(py, px, lh);
+                    if (m < NPIX) {
+                        *reinterpret_cast<f32x4 *>(dst) = __builtin_bit_cast(f32x4, hi);
+                        *reinterpret_cast<f32x4 *>(dst + 2 * C::PLANE) = __builtin_bit_cast(f32x4, lo);
+                    }
+                }
+            }
+        };
+        if constexpr (HEADF) {
+            const float *xin = p.x + (int64_t)f * p.x_fs;
+            const int64_t plane = (int64_t)p.H * p.W;
+            for (int e = tid; e < RPH * RPW; e += 256) {
+                const int ry = e / RPW, rx = e - ry * RPW;
+                const int gy = iy0 - 1 + ry, gx = ix0 - 1 + rx;
+                const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                _Float16 h4[4], l4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = (ok && c < p.head_cin) ? xin[c * plane + (int64_t)gy * p.W + gx] : 0.f;
+                    h4[c] = (_Float16)v;
+                    l4[c] = lo_keep((_Float16)(v - (float)h4[c]));
+                }
+                typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                u32x4 o;
+                o[0] = __builtin_bit_cast(unsigned, f16x2{h4[0], h4[1]}); o[1] = __builtin_bit_cast(unsigned, f16x2{h4[2], h4[3]});
+                o[2] = __builtin_bit_cast(unsigned, f16x2{l4[0], l4[1]}); o[3] = __builtin_bit_cast(unsigned, f16x2{l4[2], l4[3]});
+                *reinterpret_cast<u32x4 *>(rawp + e * 16) = o;
+            }
+        }
+        else if constexpr (PAIRPF) { prefetch_pair(0); publish_even(patch_buf); }
         else if constexpr (PAIR) fill_pair(0, patch_buf);
         else if constexpr (FLAT) fill_flat(chunk_src(0), patch_buf);
         else fill_patch(chunk_src(0), patch_buf);
@@ -664,6 +744,10 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                                                                              __builtin_bit_cast(f16x8, av[mt]), acc[mt][nt], 0, 0, 0);
             };
             for (int cb = 0; cb < ncb; ++cb) {
+                if constexpr (HEADF) {
+                    // both patch buffers are free here (the barrier that ended chunk cb - 1): fill them with chunks cb, cb + 1
+                    if ((cb & 1) == 0) { head_pair(cb >> 1); __syncthreads(); }
+                }
                 const float *pcur = patch_buf + (cb & 1) * C::PATCH_FLOATS;
                 float *pnext = patch_buf + ((cb + 1) & 1) * C::PATCH_FLOATS;
                 ChunkSrc cn = chunk_src(cb + 1 < ncb ? cb + 1 : cb);
@@ -677,7 +761,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
 #define BSVD_APF_TAP(T, HC, LC, HN, LN, BCUR, BFILL, SNEW, SOLD)                                                           \
                 {                                                                                                        \
                     load_b(step + 2 < nsteps ? step + 2 : nsteps - 1, BFILL);                                            \
-                    slice_load(cn, (T) * C::ROWS_PER_SLICE, SNEW);                          /* rows >= PH: zeros */       \
+                    if constexpr (!HEADF) slice_load(cn, (T) * C::ROWS_PER_SLICE, SNEW);    /* rows >= PH: zeros */       \
                     __builtin_amdgcn_sched_barrier(0);                                                                   \
                     pass(LC, BCUR, 0);                                                      /* hi(w) x lo(x) */           \
                     __builtin_amdgcn_sched_barrier(0);                                                                   \
@@ -688,7 +772,8 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     __builtin_amdgcn_sched_barrier(0);                                      /* reads stay HERE: 16 MFMAs of cover */ \
                     pass(HC, BCUR, 1);                                                      /* lo(w) x hi(x) */           \
                     pass(HC, BCUR, 0);                                                      /* hi(w) x hi(x) */           \
-                    if ((T) >= BSVD_TUNE_D && (T) <= C::NSLICE - 1 + BSVD_TUNE_D) slice_store(pnext, ((T) - BSVD_TUNE_D) * C::ROWS_PER_SLICE, SOLD); \
+                    if constexpr (!HEADF)                                                                                \
+                        if ((T) >= BSVD_TUNE_D && (T) <= C::NSLICE - 1 + BSVD_TUNE_D) slice_store(pnext, ((T) - BSVD_TUNE_D) * C::ROWS_PER_SLICE, SOLD); \
                     ++step;                                                                                              \
                 }
                 BSVD_APF_TAP(0, hiA, loA, hiB, loB, b0, b2, s0, S_OLD0)
@@ -705,6 +790,10 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
             }
         } else
         for (int cb = 0; cb < ncb; ++cb) {
+            if constexpr (HEADF) {
+                // both patch buffers are free here (the barrier that ended chunk cb - 1): fill them with chunks cb, cb + 1
+                if ((cb & 1) == 0) { head_pair(cb >> 1); __syncthreads(); }
+            }
             const float *pcur = patch_buf + (C::DBUF ? (cb & 1) * C::PATCH_FLOATS : 0);
             float *pnext = patch_buf + (C::DBUF ? ((cb + 1) & 1) * C::PATCH_FLOATS : 0);
             // next chunk's source; after the last chunk a zero-size descriptor turns the slice loads into no-ops
@@ -723,9 +812,9 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     f32x4 a[C::MT][2];                                                                         \
                     load_a(pcur, ky, (KX), a);                                                                 \
                     load_b(step + C::RING - 1 < nsteps ? step + C::RING - 1 : nsteps - 1, BFILL);              \
-                    if constexpr (C::DBUF) slice_load(cn, tap * C::ROWS_PER_SLICE, SNEW);   /* rows >= PH: zeros */ \
+                    if constexpr (C::DBUF && !HEADF) slice_load(cn, tap * C::ROWS_PER_SLICE, SNEW);   /* rows >= PH: zeros */ \
                     mfma32(a, BCUR);                                                                           \
-                    if constexpr (C::DBUF)                                                                     \
+                    if constexpr (C::DBUF && !HEADF)                                                           \
                         if (tap >= BSVD_TUNE_D && tap <= C::NSLICE - 1 + BSVD_TUNE_D) slice_store(pnext, (tap - BSVD_TUNE_D) * C::ROWS_PER_SLICE, SOLD); \
                     ++step;                                                                                    \
                 }
@@ -1111,12 +1200,13 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
     TL(3);
 }
 
-template <class C, bool FAST, int PREC, bool MIXF = false>
+template <class C, bool FAST, int PREC, bool MIXF = false, bool HEADF = false>
 static int launch_cfg(const ConvParams &pin, hipStream_t stream, char *name = nullptr, int name_len = 0)
 {
     if (name) {      // dry run: report the instantiation bsvd_conv3x3 would launch (used by bench.py's per-kernel timing)
-        snprintf(name, name_len, "conv3x3_kernel<%d,%d,%d,%d,%d>[%s]%s%s", C::MT, C::NT, C::WM, C::WN, C::STRIDE,
-                 PREC == 1 ? "f16x3" : "f32", FAST ? (MIXF ? "[fold8]" : "") : "[generic]", pin.y_planar_ch > 0 ? "[planar out]" : "");
+        snprintf(name, name_len, "conv3x3_kernel<%d,%d,%d,%d,%d>[%s]%s%s%s", C::MT, C::NT, C::WM, C::WN, C::STRIDE,
+                 PREC == 1 ? "f16x3" : "f32", FAST ? (MIXF ? "[fold8]" : "") : "[generic]", pin.y_planar_ch > 0 ? "[planar out]" : "",
+                 HEADF ? "[fused entry]" : "");
         return 0;
     }
     ConvParams p = pin;
@@ -1128,9 +1218,10 @@ static int launch_cfg(const ConvParams &pin, hipStream_t stream, char *name = nu
     const int64_t nblk = (int64_t)p.frames * p.nty * p.ntx * p.nct;
     if (nblk <= 0 || nblk > 0x7fffffff) { set_error("bsvd_conv3x3: grid of %lld workgroups", (long long)nblk); return -1; }
     static std::atomic<int> granted[MAX_DEVICES];
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv3x3_kernel<C, FAST, PREC, MIXF>), C::LDS_BYTES, granted);
+    constexpr int LDS = C::LDS_BYTES + (HEADF ? (C::TH + 4) * (C::TW + 4) * 16 : 0);      // + the raw input patch of the fused entry
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv3x3_kernel<C, FAST, PREC, MIXF, HEADF>), LDS, granted);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((conv3x3_kernel<C, FAST, PREC, MIXF>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv3x3_kernel<C, FAST, PREC, MIXF, HEADF>), dim3((unsigned)nblk), dim3(256), LDS, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -1177,6 +1268,10 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
 #ifndef BSVD_TUNE_S2_SPLIT
 #define BSVD_TUNE_S2_SPLIT 0       // 0: 8x16-px tile, single patch buffer; 1: 4x16-px tile, double-buffered
 #endif
+        if (p.head_w) {                  // fused network entry (validated by the ABI layer): the 64-channel tile with the first conv inside
+            if (stride != 1 || p.fold != 0 || p.Cout > 64 || (p.Cin & 31)) { set_error("bsvd_conv3x3: fused entry needs stride 1, fold 0, Cin %% 32 == 0, Cout <= 64"); return -18; }
+            return launch_cfg<ConvCfg<4, 1, 2, 2, 1, 3>, true, 1, false, true>(p, stream, name, name_len);
+        }
         if (p.y_planar_ch > 0) {         // network exit: 256 px x 32 ch tiles, planar fp32 epilogue
             if (stride != 1 || p.fold != 0 || p.Cout > 32) { set_error("bsvd_conv3x3: planar split output needs stride 1, fold 0, Cout <= 32"); return -16; }
             return launch_cfg<ConvCfg<2, 1, 4, 1, 1, 3>, true, 1>(p, stream, name, name_len);

@@ -5,6 +5,7 @@ tensor hand-over at the nn.Module boundary.  All arithmetic happens in the hand-
 There is deliberately no CPU path: without a HIP device / the built library this module raises.
 """
 import ctypes
+import os
 
 import torch
 
@@ -22,6 +23,16 @@ def require_hip():
 
 def _stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def head_fusable(inc0, inc3, precision):
+    """Can InputCvBlock's two convs (bsvd_arch.py:207-216) run as ONE launch (BsvdConvArgs.head_w_packed)?  Split-fp16 mode,
+    a 3/4-channel planar entry layer whose (padded) output is whole 32-channel pairs, and a plain stride-1 second conv with
+    <= 64 output channels under the same activation.  ``BSVD_FUSE_HEAD=0`` switches the fusion off (A/B measurements)."""
+    return (precision == "f16x3" and os.environ.get("BSVD_FUSE_HEAD", "1") != "0"
+            and inc0.cin in (3, 4) and inc0.cin_pad == 16 and inc0.stride == 1 and not inc0.tsm and inc0.epilogue == EPI_PLAIN
+            and inc0.cout_pad % 32 == 0 and inc3.cin_pad == inc0.cout_pad and inc3.cout_pad <= 64 and inc3.stride == 1
+            and not inc3.tsm and inc3.epilogue == EPI_PLAIN and inc0.act == inc3.act)
 
 
 class PackedNet:
@@ -56,6 +67,21 @@ class PackedNet:
                                            wp.data_ptr(), bp.data_ptr(), _stream_ptr())
                 _lib.check(rc, "bsvd_pack_weights(%s)" % sp.key)
                 self.tensors[sp.key] = (wp, bp)
+            # fused network entry: the first conv's weights as the MFMA operand of the second conv's kernel, keyed by the
+            # second conv (only DenBlock 1 has a planar entry layer)
+            self.head = {}
+            blk = getattr(net, "temp1", None)
+            if blk is not None and "inc0" in blk and "inc3" in blk and head_fusable(blk["inc0"], blk["inc3"], precision):
+                sp0, sp3 = blk["inc0"], blk["inc3"]
+                w = state[sp0.key + ".weight"].detach().to(device=device, dtype=torch.float32).contiguous()
+                b = state.get(sp0.key + ".bias")
+                b = None if b is None else b.detach().to(device=device, dtype=torch.float32).contiguous()
+                hw = torch.empty(lib.bsvd_packed_head_weight_bytes(sp0.cout_pad) // 4, dtype=torch.float32, device=device)
+                hb = torch.empty(sp0.cout_pad, dtype=torch.float32, device=device)
+                rc = lib.bsvd_pack_head_weights(w.data_ptr(), b.data_ptr() if b is not None else None, sp0.cin, sp0.cout,
+                                                sp0.cout_pad, hw.data_ptr(), hb.data_ptr(), _stream_ptr())
+                _lib.check(rc, "bsvd_pack_head_weights(%s)" % sp0.key)
+                self.head[sp3.key] = (hw, hb, sp0)
             # The packed tensors are read from whatever stream a later forward runs on (ClipPipeline's compute stream,
             # the A/B streams of streaming_forward, a graph replay): finish the one-time pack here so no consumer can see
             # half-packed weights.  (The w/b temporaries are consumed by kernels queued on this stream.)
@@ -150,12 +176,29 @@ class HipExecutor:
         self.launches += 1
         return y
 
+    def fuse_head(self, S):
+        """True if block ``S``'s entry pair inc0 -> inc3 runs as one launch (see head_fusable)"""
+        return "inc3" in S and S["inc3"].key in getattr(self.packed, "head", {})
+
+    def conv_head_fused(self, sp0, sp3, x, out=None):
+        """InputCvBlock in one launch: x planar [T,C,H,W] -> act(conv(act(conv(x, sp0)), sp3)) as NHWC split16; the
+        intermediate tensor never exists in HBM."""
+        a, y = self.build_args(sp3, x, x_planar=True, out=out, head=sp0)
+        if self.record_variants:
+            buf = ctypes.create_string_buffer(96)
+            _lib.check(self.lib.bsvd_conv3x3_variant(ctypes.byref(a), buf, 96), "bsvd_conv3x3_variant(%s)" % sp3.key)
+            self.last_variant = buf.value.decode()
+        rc = self.lib.bsvd_conv3x3(ctypes.byref(a), _stream_ptr())
+        _lib.check(rc, "bsvd_conv3x3(%s + %s)" % (sp0.key, sp3.key))
+        self.launches += 1
+        return y
+
     @staticmethod
     def lib_args_type():
         return _lib.BsvdConvArgs
 
     def build_args(self, sp, x, halo_prev=None, halo_next=None, extra=None, extra_pstride=0, extra_cstride=1,
-                   x_planar=False, y_planar=None, out=None, alloc=True):
+                   x_planar=False, y_planar=None, out=None, alloc=True, head=None):
         """Validates one fused layer and fills its ``BsvdConvArgs``; returns (args, y).  ``alloc=False`` leaves ``y`` (and
         ``args.y``) unset for the caller to supply per launch (the stream plan's exit layer)."""
         a = _lib.BsvdConvArgs()
@@ -166,7 +209,15 @@ class HipExecutor:
             if t is not None and (not t.is_cuda or t.dtype != torch.float32 or t.device != x.device):
                 raise ValueError("%s: %s must be a float32 tensor on %s (got %s on %s)"
                                  % (sp.key, name, x.device, t.dtype, t.device))
-        if x_planar:
+        if x_planar and head is not None:
+            T, C, H, W = x.shape
+            hw, hb, sp0 = self.packed.head[sp.key]
+            if sp0 is not head or C != head.cin:
+                raise ValueError("%s: fused entry expects the %d-channel planar input of %s" % (sp.key, head.cin, head.key))
+            a.x_planar_ch = C
+            a.x_frame_stride = C * H * W
+            a.head_w_packed, a.head_bias = hw.data_ptr(), hb.data_ptr()
+        elif x_planar:
             T, C, H, W = x.shape
             if C != sp.cin or sp.cin_pad != 16 or sp.stride != 1 or sp.tsm:
                 raise ValueError("%s: planar input needs a plain stride-1 layer with <= 4 input channels" % sp.key)

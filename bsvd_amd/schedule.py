@@ -36,6 +36,11 @@ def planar_ok(ex, net):
     return (first.cin in (3, 4) and first.cin_pad == 16), (last.cout <= 4 and last.cout_pad == 16)
 
 
+def _fused_head(ex, S):
+    fn = getattr(ex, "fuse_head", None)
+    return bool(fn and fn(S))
+
+
 def denblock_clip(ex, S, x, halo_fn=None, x_planar=False, y_planar=None):
     """One DenBlock over a clip.  x: [T,H,W,cin_pad] NHWC (or planar [T,C,H,W] with x_planar).
     halo_fn(spec, x) -> (Halo|None, Halo|None) supplies the neighbour shards' boundary slices when the clip
@@ -60,9 +65,12 @@ def denblock_clip(ex, S, x, halo_fn=None, x_planar=False, y_planar=None):
         hp, hn = halo_fn(sp, v)
         return ex.conv(sp, v, halo_prev=hp, halo_next=hn)
 
-    a = ex.conv(S["inc0"], x, x_planar=True) if x_planar else ex.conv(S["inc0"], x)
-    x0 = ex.conv(S["inc3"], a)
-    del a
+    if x_planar and _fused_head(ex, S):
+        x0 = ex.conv_head_fused(S["inc0"], S["inc3"], x)          # InputCvBlock in one launch (engine.head_fusable)
+    else:
+        a = ex.conv(S["inc0"], x, x_planar=True) if x_planar else ex.conv(S["inc0"], x)
+        x0 = ex.conv(S["inc3"], a)
+        del a
     d = ex.conv(S["down0"], x0)
     x1 = tsm("d0c2", tsm("d0c1", d))
     d = ex.conv(S["down1"], x1)
@@ -167,7 +175,10 @@ class _DenBlockStream:
         self.skip_in.push(x)
         x0 = None
         if x is not None:
-            x0 = ex.conv(S["inc3"], ex.conv(S["inc0"], x, x_planar=True) if x_planar else ex.conv(S["inc0"], x))
+            if x_planar and _fused_head(ex, S):
+                x0 = ex.conv_head_fused(S["inc0"], S["inc3"], x)
+            else:
+                x0 = ex.conv(S["inc3"], ex.conv(S["inc0"], x, x_planar=True) if x_planar else ex.conv(S["inc0"], x))
         self.skip_x0.push(x0)
         d = None if x0 is None else ex.conv(S["down0"], x0)
         x1 = self._pair(ex, "d0c1", "d0c2", d)

@@ -92,6 +92,21 @@ class _Recorder:
         self.rec.append((sp, x, halo_prev, halo_next, extra, extra_pstride, extra_cstride, x_planar, y_planar, o))
         return o
 
+    def fuse_head(self, S):
+        fn = getattr(self.eng.ex, "fuse_head", None)
+        return bool(fn and fn(S))
+
+    def conv_head_fused(self, sp0, sp3, x, out=None):
+        """the fused entry pair as ONE recorded launch writing inc3's ring (inc0's ring stays unused)"""
+        ring = self.eng.rings[sp3.key]
+        n = self.count.get(sp3.key, 0)
+        self.count[sp3.key] = n + 1
+        o = ring[n % len(ring)]
+        if x.shape[0] != o.shape[0]:
+            o = o[:x.shape[0]]
+        self.rec.append((sp3, x, None, None, None, 0, 1, True, None, o, sp0))
+        return o
+
     def take(self):
         rec, self.rec = self.rec, []
         return rec
@@ -218,14 +233,18 @@ class StreamEngine:
             if self.hip:
                 plan.args = (self.ex.lib_args_type() * max(plan.n, 1))()
                 for i, r in enumerate(rec):
-                    plan.args[i], _ = self.ex.build_args(*r[:9], out=r[9])
+                    plan.args[i], _ = self.ex.build_args(*r[:9], out=r[9], head=r[10] if len(r) > 10 else None)
             self.plans[sig] = plan
         return y, sig, plan
 
     # ---- issuing -------------------------------------------------------------------------------
     def _issue_generic(self, plan):
         """plain executor (CPU tests): layer by layer, in order"""
-        for sp, x, hp, hn, extra, eps, ecs, xpl, ypl, o in plan.rec:
+        for r in plan.rec:
+            sp, x, hp, hn, extra, eps, ecs, xpl, ypl, o = r[:10]
+            if len(r) > 10:
+                self.ex.conv_head_fused(r[10], sp, x, out=o)
+                continue
             self.ex.conv(sp, x, halo_prev=hp, halo_next=hn, extra=extra, extra_pstride=eps, extra_cstride=ecs,
                          x_planar=xpl, y_planar=ypl, out=o)
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BSVD_ABI_VERSION 7
+#define BSVD_ABI_VERSION 8
 
 /* dtype.  BSVD_F32: exact fp32 (v_mfma_f32_32x32x2_f32).  BSVD_F16X3 ("split16"): every fp32 value v is carried as
  * an fp16 pair hi = fp16(v), lo = fp16(v - hi); a 16-channel chunk of a pixel is stored as [hi x16 | lo x16] in the
@@ -105,6 +105,15 @@ typedef struct BsvdConvArgs {
                                  * are identical; a layer-major host alternates it layer by layer so that every layer starts with
                                  * the part of its input the previous layer wrote LAST -- still in the 256 MiB Infinity Cache when
                                  * the clip's tensors (0.3-1.3 GB) are not (+0.3 % on the 10-frame 540x960 clip)          */
+    /* Fused network entry (ABI v8, BSVD_F16X3 only): InputCvBlock's two convs (bsvd_arch.py:207-216) in ONE launch.
+     * With x_planar_ch > 0 AND head_w_packed != NULL, x is the caller's planar tensor [frames][x_planar_ch][H][W] fp32 (3 or 4
+     * channels) and the kernel computes  t = act(conv3x3(x, head_w) + head_bias)  (x_planar_ch -> Cin channels, zero outside
+     * the image) on every tile's 18 x 18 patch itself -- on the matrix cores, K = 36 padded to 48, straight into the LDS
+     * patch of the main conv -- and then  y = epilogue(act(conv3x3(t, w_packed) + bias)).  The Cin-channel tensor t never
+     * exists in HBM (1.33 GB written + read per 10-frame 540x960 clip).  Needs Cin % 32 == 0, Cout <= 64, stride 1, fold 0,
+     * BSVD_EPI_PLAIN; both convs share `act`.  head_w_packed: bsvd_pack_head_weights(); head_bias: [Cin] fp32. */
+    const void *head_w_packed;
+    const void *head_bias;
 } BsvdConvArgs;
 
 int bsvd_abi_version(void);
@@ -131,6 +140,16 @@ int64_t bsvd_packed_weight_elems(int32_t Cin_pad, int32_t Cout_pad);
 int bsvd_pack_weights(const float *w_oihw, const float *bias, int32_t Cin, int32_t Cout,
                       int32_t Cin_pad, int32_t Cout_pad, int32_t pixel_shuffle, int32_t dtype,
                       void *w_packed, void *bias_packed, void *stream);
+
+/*
+ * Weights of the fused network entry (BsvdConvArgs.head_w_packed): the first conv's [Cmid][Cin][3][3] (Cin = 3 or 4) as the
+ * A operand of v_mfma_f32_32x32x16_f16 -- [Cmid_pad/32 channel pairs][3 k-steps][64 lanes][hi x8 | lo x8] fp16 with
+ * k = tap*4 + channel (36 real of 48) -- plus head_bias[Cmid_pad] fp32 (zero padded).  w_packed needs
+ * bsvd_packed_head_weight_bytes(Cmid_pad) bytes.
+ */
+int64_t bsvd_packed_head_weight_bytes(int32_t Cmid_pad);
+int bsvd_pack_head_weights(const float *w_oihw, const float *bias, int32_t Cin, int32_t Cmid, int32_t Cmid_pad,
+                           void *w_packed, float *bias_packed, void *stream);
 
 /*
  * Clip entry/exit: the reference feeds NCHW tensors (BSVD.forward reshape, bsvd_arch.py:494-499,

@@ -225,3 +225,58 @@ def test_c32_sized_sharded_equals_unsharded_split():
     assert not errors, errors
     assert torch.equal(torch.cat(results), whole)
     assert maxabs(whole.cpu().numpy(), g["out"][0]) < TIGHT
+
+
+@pytest.mark.parametrize("cin,cmid,cout,act,T,H,W", [
+    (4, 64, 64, "relu6", 2, 20, 36),        # bsvd_c64's entry pair, ragged tiles
+    (4, 64, 64, "relu6", 1, 33, 50),
+    (3, 30, 64, "relu", 2, 17, 21),         # blind: 3-channel input, interm_ch 30 riding on two zero padding channels, unbounded ReLU
+    (4, 32, 32, "relu6", 1, 16, 16),        # c32-sized network: one chunk pair, half of the 64-channel tile masked
+    (4, 64, 64, "none", 1, 1, 5),           # degenerate image
+])
+def test_fused_entry_vs_two_step_oracle_and_vs_the_unfused_kernels(cin, cmid, cout, act, T, H, W, monkeypatch):
+    """InputCvBlock (bsvd_arch.py:194-226) as ONE launch (BsvdConvArgs.head_w_packed): the first conv is computed on every
+    tile's patch by MFMAs inside the second conv's kernel.  Against the CPU oracle's two convs (the intermediate is zero
+    OUTSIDE the image -- the second conv's padding --, not the first conv of a padded image), and against the two separate
+    HIP launches."""
+    import torch
+    from bsvd_amd.engine import HipExecutor, PackedNet
+    from bsvd_amd.netspec import ConvSpec, pad16
+    from oracle_exec import OracleExecutor
+    from seeded import seeded_state
+    dev = torch.device("cuda", 0)
+
+    class Net:
+        pass
+
+    sp0 = ConvSpec("inc0", "b.inc.convblock.0", cin, cmid, 1, False, act, 0)
+    sp3 = ConvSpec("inc3", "b.inc.convblock.3", cmid, cout, 1, False, act, 0)
+    net = Net()
+    net.layers = [sp0, sp3]
+    net.temp1 = {"inc0": sp0, "inc3": sp3}
+    st = seeded_state([(sp0.key + ".weight", (cmid, cin, 3, 3)), (sp0.key + ".bias", (cmid,)),
+                       (sp3.key + ".weight", (cout, cmid, 3, 3)), (sp3.key + ".bias", (cout,))], 17)
+    rs = np.random.RandomState(cin + cmid + H)
+    x = torch.from_numpy(rs.standard_normal((T, cin, H, W)).astype(np.float32))
+    oex = OracleExecutor(st, double=True)
+    want = oex.conv(sp3, oex.conv(sp0, x, x_planar=True))
+    ex = HipExecutor(PackedNet(net, {k: torch.as_tensor(v) for k, v in st.items()}, dev, "f16x3"))
+    assert ex.fuse_head(net.temp1)
+    ex.record_variants = True
+    got = ex.conv_head_fused(sp0, sp3, x.to(dev))
+    assert "[fused entry]" in ex.last_variant, ex.last_variant
+    two = ex.conv(sp3, ex.conv(sp0, x.to(dev), x_planar=True))
+    torch.cuda.synchronize()
+
+    def unsplit(t):          # split16 [.., C_pad] (hi x16 | lo x16 per chunk) -> fp32 channels
+        h = t.view(torch.float16).reshape(*t.shape[:-1], t.shape[-1] // 16, 2, 16).float()
+        return (h[..., 0, :] + h[..., 1, :]).reshape(*t.shape[:-1], t.shape[-1])
+
+    g, tw = unsplit(got.cpu()), unsplit(two.cpu())
+    scale = max(1.0, float(want.abs().max()))
+    assert maxabs(g.numpy(), want.numpy()) < 2e-5 * scale, (maxabs(g.numpy(), want.numpy()), scale)
+    assert maxabs(g.numpy(), tw.numpy()) < 2e-5 * scale
+    assert float(g[..., cout:].abs().max()) == 0.0 if pad16(cout) > cout else True
+    monkeypatch.setenv("BSVD_FUSE_HEAD", "0")
+    ex2 = HipExecutor(PackedNet(net, {k: torch.as_tensor(v) for k, v in st.items()}, dev, "f16x3"))
+    assert not ex2.fuse_head(net.temp1)
