@@ -150,6 +150,8 @@ class StreamEngine:
         # of DenBlock 1 reads them again 8 steps later (MemSkip skip1, bsvd_arch.py:378,394)
         ring("input", (n, in_ch, H, W), 10)
         exit_key = net.temp2["out3"].key
+        fuse = getattr(ex, "fuse_head", None)
+        fused_entry = net.temp1["inc0"].key if (fuse and fuse(net.temp1)) else None     # its output never exists (engine.head_fusable)
         for blk in (net.temp1, net.temp2):
             h, w = H, W
             for name, sp in blk.items():
@@ -162,6 +164,8 @@ class StreamEngine:
                     h, w = ho, wo
                 if sp.key == exit_key:          # planar [n, out_ch, H, W]: what the caller gets a copy of
                     shape = (n, sp.cout, ho, wo)
+                if sp.key == fused_entry:
+                    continue
                 ring(sp.key, shape, ring_depth(name, blk is net.temp1 and name == "out3", sp.key == exit_key))
         self.t1 = _DenBlockStream(net.temp1)
         self.t2 = _DenBlockStream(net.temp2)

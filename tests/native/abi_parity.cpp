@@ -173,6 +173,50 @@ static void case_split_chain() {
     report("split-fp16 chain: planar in -> 4->64 -> 64->64 (f16x3) -> 64->3 resid+clamp", maxabs(got, want), 1e-3);
 }
 
+// The same chain with InputCvBlock's two convs as ONE launch (ABI v8, BsvdConvArgs.head_w_packed): planar in -> [4->64 -> 64->64]
+// fused -> 64->3.  Against the plain-C oracle, and against the three-launch chain above (same arithmetic class, not bitwise:
+// the fused entry computes the 4->64 conv with split-fp16 MFMAs, the stand-alone entry kernel with exact fp32 FMAs).
+static void case_fused_entry() {
+    const int T = 2, H = 24, W = 40, C = 64;
+    auto x = randv((size_t)T * 4 * H * W, 1.f);
+    auto w1 = randv((size_t)C * 4 * 9, 0.3f), b1 = randv(C, 0.1f);
+    auto w2 = randv((size_t)C * C * 9, 0.06f), b2 = randv(C, 0.1f);
+    auto w3 = randv((size_t)3 * C * 9, 0.06f), b3 = randv(3, 0.1f);
+    float *dx = dev(x), *d2 = dev_zeros((size_t)T * H * W * C), *dy = dev_zeros((size_t)T * 3 * H * W);
+    float *dw1 = dev(w1), *db1 = dev(b1);
+    void *hw = nullptr; float *hb = nullptr;
+    HIP_OK(hipMalloc(&hw, (size_t)bsvd_packed_head_weight_bytes(C))); HIP_OK(hipMalloc((void **)&hb, sizeof(float) * C));
+    ABI_OK(bsvd_pack_head_weights(dw1, db1, 4, C, C, hw, hb, nullptr));
+    if (bsvd_pack_head_weights(dw1, db1, 5, C, C, hw, hb, nullptr) != -5) { printf("pack_head_weights must refuse 5 input channels\n"); ++failures; }
+    Packed p2 = pack(w2, b2, C, C, C, C, 0, BSVD_F16X3);
+    Packed p3 = pack(w3, b3, C, 3, C, 16, 0, BSVD_F16X3);
+    BsvdConvArgs a; memset(&a, 0, sizeof(a));
+    a.x = dx; a.x_frame_stride = (int64_t)4 * H * W; a.x_planar_ch = 4; a.head_w_packed = hw; a.head_bias = hb;
+    a.w_packed = p2.w; a.bias_packed = p2.b; a.y = d2; a.y_frame_stride = (int64_t)H * W * C;
+    a.frames = T; a.H = H; a.W = W; a.Cin = C; a.Cout = C; a.stride = 1; a.act = BSVD_ACT_RELU6; a.dtype = BSVD_F16X3;
+    char name[96];
+    ABI_OK(bsvd_conv3x3_variant(&a, name, sizeof(name)));
+    if (!strstr(name, "[fused entry]")) { printf("variant of the fused entry: %s\n", name); ++failures; }
+    ABI_OK(bsvd_conv3x3(&a, nullptr));
+    BsvdConvArgs bad = a; bad.dtype = BSVD_F32;
+    if (bsvd_conv3x3(&bad, nullptr) != -18) { printf("the fused entry must refuse BSVD_F32: %s\n", bsvd_last_error()); ++failures; }
+    memset(&a, 0, sizeof(a));
+    a.x = d2; a.x_frame_stride = (int64_t)H * W * C; a.w_packed = p3.w; a.bias_packed = p3.b; a.y = dy; a.y_frame_stride = (int64_t)3 * H * W;
+    a.extra = dx; a.extra_frame_stride = (int64_t)4 * H * W; a.extra_pstride = 1; a.extra_cstride = H * W; a.resid_ch = 3;
+    a.frames = T; a.H = H; a.W = W; a.Cin = C; a.Cout = 16; a.stride = 1; a.act = BSVD_ACT_NONE; a.epilogue = BSVD_EPI_RESID;
+    a.dtype = BSVD_F16X3; a.y_planar_ch = 3;
+    ABI_OK(bsvd_conv3x3(&a, nullptr)); HIP_OK(hipDeviceSynchronize());
+    auto got = host(dy, (size_t)T * 3 * H * W);
+    std::vector<float> want((size_t)T * 3 * H * W), t1((size_t)C * H * W), t2((size_t)C * H * W);
+    for (int t = 0; t < T; ++t) {
+        const float *xf = x.data() + (size_t)t * 4 * H * W;
+        if (oracle_conv3x3(xf, nullptr, nullptr, 0, w1.data(), b1.data(), 4, C, H, W, 1, 2, 0, nullptr, t1.data())) exit(4);
+        if (oracle_conv3x3(t1.data(), nullptr, nullptr, 0, w2.data(), b2.data(), C, C, H, W, 1, 2, 0, nullptr, t2.data())) exit(4);
+        if (oracle_conv3x3(t2.data(), nullptr, nullptr, 0, w3.data(), b3.data(), C, 3, H, W, 1, 0, 2, xf, want.data() + (size_t)t * 3 * H * W)) exit(4);
+    }
+    report("fused entry: planar in -> [4->64 -> 64->64] in one launch (f16x3) -> 64->3 resid", maxabs(got, want), 1e-3);
+}
+
 // One streaming step as one submission (ABI v6): the three-layer split chain issued with bsvd_conv3x3_batch, then captured
 // into a HIP graph on a created stream and replayed on another; both must reproduce the layer-by-layer result bit for bit.
 static void case_batch_and_graph() {
@@ -266,7 +310,7 @@ int main() {
     if (bsvd_abi_version() != BSVD_ABI_VERSION || bsvd_conv_args_size() != (int)sizeof(BsvdConvArgs)) { printf("ABI mismatch\n"); return 1; }
     int n = 0; HIP_OK(hipGetDeviceCount(&n)); if (n < 1) { printf("no HIP device\n"); return 1; }
     HIP_OK(hipSetDevice(0));
-    case_tsm(); case_stride2(); case_pixel_shuffle(); case_split_chain(); case_batch_and_graph(); case_stream_ring_graphs();
+    case_tsm(); case_stride2(); case_pixel_shuffle(); case_split_chain(); case_fused_entry(); case_batch_and_graph(); case_stream_ring_graphs();
     printf(failures ? "abi_parity: %d FAILED\n" : "abi_parity: all cases ok\n", failures);
     return failures ? 1 : 0;
 }

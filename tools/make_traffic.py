@@ -15,11 +15,13 @@ import collections, csv, glob, json, os, re, sys
 
 def kernel_key(name):
     """rocprof kernel name -> the variant names bench.py uses (LaunchTimer.variant)."""
-    m = re.search(r"conv3x3_kernel<bsvd::ConvCfg<(\d+), (\d+), (\d+), (\d+), (\d+), \d+(?:, (?:true|false))?>, (true|false), (\d)(?:, (true|false))?>", name)
+    m = re.search(r"conv3x3_kernel<bsvd::ConvCfg<(\d+), (\d+), (\d+), (\d+), (\d+), \d+(?:, (?:true|false))?>, (true|false), (\d)(?:, (true|false))?(?:, (true|false))?>", name)
     if m:
-        mt, nt, wm, wn, st, fast, prec, mix = m.groups()
-        return "conv3x3_kernel<%s,%s,%s,%s,%s>%s%s" % (mt, nt, wm, wn, st, "[f16x3]" if prec == "1" else "[f32]",
-                                                      ("[fold8]" if mix == "true" else "") if fast == "true" else "[generic]")
+        mt, nt, wm, wn, st, fast, prec, mix, headf = m.groups()
+        planar = "[planar out]" if (mt, nt, wm, wn) == ("2", "1", "4", "1") and prec == "1" else ""     # the exit tile's only use
+        return "conv3x3_kernel<%s,%s,%s,%s,%s>%s%s%s%s" % (mt, nt, wm, wn, st, "[f16x3]" if prec == "1" else "[f32]",
+                                                          ("[fold8]" if mix == "true" else "") if fast == "true" else "[generic]",
+                                                          planar, "[fused entry]" if headf == "true" else "")
     m = re.search(r"(head|tail)_kernel<(\d)>", name)
     if m:
         return m.group(0)          # bench.py appends the mode tag; match on the prefix
