@@ -333,6 +333,7 @@ class BSVD(_HipNet):
         for eng in self._stream_engs.values():
             eng.release()
         self._stream_engs, self._stream_key = {}, None
+        self.__dict__.pop("_ring_oom", None)          # memory may be there again: let the next stream try its rings afresh
 
     @property
     def _stream_eng(self):

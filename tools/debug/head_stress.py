@@ -7,7 +7,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
 import bench
 dev = torch.device("cuda", 0)
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
-side_mode = sys.argv[2] if len(sys.argv) > 2 else "conv"      # conv | none | copy | otherprec
+side_mode = sys.argv[2] if len(sys.argv) > 2 else "conv"      # conv | none | copy | otherprec | fused (the fused entry kernel under test, conv alongside)
 m = bench.build_model(dev, prec)
 ex = m._executor(dev)
 net = m.net
@@ -17,7 +17,9 @@ sp0, sp3 = net.temp1["inc0"], net.temp1["inc3"]
 torch.manual_seed(0)
 for (T, H, W) in ((1, 64, 96), (3, 64, 96), (1, 540, 960)):
     x = torch.rand((T, 4, H, W), device=dev)
-    ref = ex.conv(sp0, x, x_planar=True).clone()
+    fused = side_mode.startswith("fused")
+    run = (lambda: ex.conv_head_fused(sp0, sp3, x)) if fused else (lambda: ex.conv(sp0, x, x_planar=True))
+    ref = run().clone()
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
     big = torch.rand((2, 270, 480, 128), device=dev)
@@ -25,13 +27,13 @@ for (T, H, W) in ((1, 64, 96), (3, 64, 96), (1, 540, 960)):
     bad = 0
     for it in range(300):
         with torch.cuda.stream(side):
-            if side_mode == "conv":
+            if side_mode in ("conv", "fused"):
                 ex.conv(spb, big)
             elif side_mode == "copy":
                 big2 = big * 1.5
             elif side_mode == "otherprec":
                 ex2.conv(spb, big)
-        y = ex.conv(sp0, x, x_planar=True)
+        y = run()
         if it % 3 == 0:
             torch.cuda.synchronize()
         if not torch.equal(y, ref):
