@@ -442,6 +442,30 @@ class BSVD(_HipNet):
                 y = ex.to_nchw(y, self.net.out_ch, self.clamp)
             return y.to(getattr(self, "_last_dtype", torch.float32))
 
+    def feed_overlapped(self, x, last=False):
+        """Per-frame feed for hosts that pipeline anyway (``pipeline.LiveStream`` with depth >= 2): like ``feedin_one_element``,
+        but DenBlock 2 runs ONE STEP BEHIND DenBlock 1 as the second branch of the step's HIP graph, so the single-frame
+        launches of two independent layer chains share the chip (540x960: 0.95 instead of 0.89 of the clip rate).  The price
+        is one feed of latency: the call returns the frame fed ``shift_num + 1`` feeds earlier (None before that).  End of
+        stream: ``shift_num + 1`` feeds of None, then one call with ``last=True`` (drains the lagging DenBlock-2 step), then
+        ``reset()``.  Same kernels on the same data as every other schedule: bit-identical frames.  Do not mix with
+        ``feedin_one_element`` inside one stream."""
+        dev = self._device()
+        with torch.no_grad(), torch.cuda.device(dev):
+            ex = self._executor(dev)
+            if x is not None:
+                if x.dim() != 4 or x.shape[0] != 1:
+                    raise ValueError("feed_overlapped expects one frame [1,C,H,W], got %s" % (tuple(x.shape),))
+                self._last_dtype = x.dtype if x.dtype in (torch.float16, torch.bfloat16) else torch.float32
+            eng = self._stream_engine(ex, x.shape[1:]) if x is not None else self._stream_eng
+            if eng is None:
+                if x is None:
+                    return None
+                raise RuntimeError("feed_overlapped needs the ring engine (stream_rings=True, planar edge layers, enough HBM); "
+                                   "use feedin_one_element")
+            y = eng.feed_lagged(x, (self.net.out_ch, self.clamp), last=last)
+            return None if y is None else y.to(getattr(self, "_last_dtype", torch.float32), copy=True)
+
     def streaming_forward(self, input_seq):
         """Pipeline-style inference over a clip (bsvd_arch.py:501-552): F data feeds, then flush feeds until
         F + shift_num results exist; the first shift_num (None) are dropped; state is reset afterwards.

@@ -132,13 +132,18 @@ class LiveStream:
 
     Frame k comes back ``model.shift_num`` (16) feeds after it went in -- the network's own latency -- plus ``depth-1``
     feeds of host pipelining (``depth=1``: every feed waits for its own step, lowest latency; ``depth>=2``: transfers of one
-    step overlap the compute of the next, highest rate).  Results keep submission order.  Not re-entrant (one stream per
-    instance, like the reference's module state)."""
+    step overlap the compute of the next, highest rate).  ``overlap_blocks`` (default: on for ``depth >= 2``) additionally lets
+    DenBlock 2 run one step behind DenBlock 1 as a parallel graph branch (``BSVD.feed_overlapped``): one more feed of latency
+    (``shift_num + depth`` in total), the single-frame launches of two independent chains share the chip.  Results keep
+    submission order and are byte-identical in every mode.  Not re-entrant (one stream per instance, like the reference's
+    module state)."""
 
-    def __init__(self, model, sigma=None, depth=2):
+    def __init__(self, model, sigma=None, depth=2, overlap_blocks=None):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.model, self.sigma, self.depth = model, sigma, depth
+        self.overlap = (depth >= 2) if overlap_blocks is None else bool(overlap_blocks)
+        self.latency = model.shift_num + depth - 1 + (1 if self.overlap else 0)     # feeds between a frame going in and coming out
         self.device = model._device()
         if self.device.type != "cuda":
             raise RuntimeError("LiveStream needs the model on a HIP device (model.cuda())")
@@ -165,7 +170,7 @@ class LiveStream:
         slot.downloaded.synchronize()
         return slot.pin_out.numpy().copy() if has_out else None
 
-    def _step(self, frame_u8):
+    def _step(self, frame_u8, last=False):
         slot = self.slots[self.count % len(self.slots)]
         self.count += 1
         with torch.cuda.device(self.device):
@@ -179,7 +184,7 @@ class LiveStream:
                 if frame_u8 is not None:
                     self.comp.wait_event(slot.uploaded)
                     x = frames_to_input(slot.dev_in, self.sigma)
-                y = self.model.feedin_one_element(x)
+                y = self.model.feed_overlapped(x, last=last) if self.overlap else self.model.feedin_one_element(x)
                 if y is not None:
                     slot.dev_out = output_to_frames(y.float())      # held by the slot until its download completed
                 slot.computed.record()
@@ -220,6 +225,8 @@ class LiveStream:
         for _ in range(self.model.shift_num + 1):
             self._step(None)
             self._drain(self.depth - 1, outs)
+        if self.overlap:                              # the lagging DenBlock-2 step of the last flush feed
+            self._step(None, last=True)
         self._drain(0, outs)
         self.model.reset()
         return outs

@@ -150,8 +150,8 @@ def test_clip_pipeline_overlapped_transfers_match_the_direct_path(depth):
         pipe.submit(np.zeros((2, 30, 50, 3), np.uint8))     # not a multiple of 4
 
 
-@pytest.mark.parametrize("depth", [1, 2, 3])
-def test_live_stream_uint8_frames_match_the_clip_path(depth):
+@pytest.mark.parametrize("depth,overlap", [(1, None), (2, None), (3, None), (2, False), (1, True)])
+def test_live_stream_uint8_frames_match_the_clip_path(depth, overlap):
     """bsvd_amd.pipeline.LiveStream: uint8 frames in, one graph-replayed pipeline step per feed, uint8 frames out
     shift_num + depth - 1 feeds later, byte-identical to the clip schedule on the same frames; reusable after flush()."""
     import bsvd_amd
@@ -165,7 +165,9 @@ def test_live_stream_uint8_frames_match_the_clip_path(depth):
     m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
     m = m.to(dev)
     sigma = 30 / 255.0
-    live = LiveStream(m, sigma=sigma, depth=depth)
+    live = LiveStream(m, sigma=sigma, depth=depth, overlap_blocks=overlap)
+    assert live.overlap == ((depth >= 2) if overlap is None else overlap)
+    assert live.latency == m.shift_num + depth - 1 + (1 if live.overlap else 0)
     for T in (23, 5):
         frames = rs.randint(0, 256, (T, 64, 96, 3)).astype(np.uint8)
         want = output_to_frames(m.clip_forward(frames_to_input(torch.from_numpy(frames).to(dev), sigma))).cpu().numpy()
@@ -175,8 +177,8 @@ def test_live_stream_uint8_frames_match_the_clip_path(depth):
             if r is not None:
                 first = k if first is None else first
                 got.append(r)
-        if T > m.shift_num + depth - 1:
-            assert first == m.shift_num + depth - 1                 # network latency + host pipelining, nothing more
+        if T > live.latency:
+            assert first == live.latency                            # network latency + host pipelining (+ 1 with overlapped blocks)
         got += live.flush()
         assert len(got) == T and all(g.dtype == np.uint8 for g in got)
         assert np.array_equal(np.stack(got), want)

@@ -22,8 +22,8 @@ m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, norm="none", act="relu6", inte
                   precision=a.precision).to(dev).eval()
 frames = np.random.RandomState(0).randint(0, 256, (a.frames, H, W, 3)).astype(np.uint8)
 res = {"size": a.size, "frames": a.frames, "precision": a.precision, "rows": []}
-for depth in (1, 2, 3):
-    live = LiveStream(m, sigma=30 / 255.0, depth=depth)
+for depth, overlap in ((1, False), (2, False), (2, True), (3, True)):
+    live = LiveStream(m, sigma=30 / 255.0, depth=depth, overlap_blocks=overlap)
     for rep in range(3):                                  # rep 0/1: plans -> graphs; rep 2 is timed
         lat = []
         t0 = time.perf_counter()
@@ -37,10 +37,10 @@ for depth in (1, 2, 3):
         n_out += len(live.flush())
         total = time.perf_counter() - t0
     assert n_out == a.frames
-    steady = np.array(lat[m.shift_num + depth:]) * 1e3
-    row = {"depth": depth, "host_to_host_fps_steady": 1e3 / float(steady.mean()), "whole_feed_fps": a.frames / total,
+    steady = np.array(lat[live.latency + 1:]) * 1e3
+    row = {"depth": depth, "overlap_blocks": overlap, "host_to_host_fps_steady": 1e3 / float(steady.mean()), "whole_feed_fps": a.frames / total,
            "feed_call_ms": {"p50": float(np.percentile(steady, 50)), "p99": float(np.percentile(steady, 99)), "max": float(steady.max())},
-           "frame_latency_feeds": m.shift_num + depth - 1}
+           "frame_latency_feeds": live.latency}
     res["rows"].append(row)
     print(json.dumps(row), flush=True)
 if a.json:
