@@ -179,6 +179,7 @@ class StreamEngine:
         self.layerwise = False      # measurement aid: issue every plan layer by layer through ex.conv (per-launch HIP events)
         self._cap = self._side = None
         self._lag = None            # streaming_forward: DenBlock 1's output of the previous step, not yet fed to DenBlock 2
+        self._mode = None
 
     # ---- state ---------------------------------------------------------------------------------
     def reset(self):
@@ -194,6 +195,7 @@ class StreamEngine:
         self.r2.reset()
         self.n_in = 0
         self._lag = None
+        self._mode = None           # 'feed' | 'lagged': the two step protocols must not be mixed inside one stream
 
     def release(self):
         """Frees graphs and rings.  Replays may still be in flight on whatever streams the caller used (LiveStream's compute
@@ -313,10 +315,19 @@ class StreamEngine:
                 _lib.check(lib.bsvd_conv3x3_batch(p.args, p.n, cur), "bsvd_conv3x3_batch")
                 self.stats["batch_launches"] += 1
 
+    def _enter(self, mode):
+        if self._mode is None:
+            self._mode = mode
+        elif self._mode != mode:
+            raise RuntimeError("this stream was started with %s steps and continued with %s steps: DenBlock 2 runs in step with "
+                               "DenBlock 1 in the one (feedin_one_element) and one step behind in the other (feed_overlapped / "
+                               "streaming_forward); reset() between them" % (self._mode, mode))
+
     # ---- the two entry points ------------------------------------------------------------------
     def feed(self, x, y_planar):
         """One ``feedin_one_element`` step: both DenBlocks of this step, in order.  Returns a VIEW of the exit ring slot
         (valid until the next-but-one step; callers copy it) or None."""
+        self._enter("feed")
         self.stats["steps"] += 1
         xin = self._stage_input(x)
         y1, s1, p1 = self._plan(self.t1, self.r1, xin, True, None)
@@ -328,6 +339,7 @@ class StreamEngine:
         """``streaming_forward`` step k: DenBlock 1 of step k and DenBlock 2 of step k-1 as two independent chains (one graph
         with two branches).  Returns DenBlock 2's result of step k-1 (a ring view; None for k = 0).  ``last``: only drain the
         lagging DenBlock-2 step (no DenBlock-1 work)."""
+        self._enter("lagged")
         self.stats["steps"] += 1
         had_lag, lag = self._lag is not None, (self._lag[0] if self._lag is not None else None)
         plans_a, plans_b, sa, sb, y2 = (), (), (), (), None

@@ -156,3 +156,19 @@ def test_random_lengths_chunks_and_lag_on_cpu(seed):
         run = _run_lagged if rs.randint(0, 2) else _run_feed
         got = run(eng, x, net.shift_num)
         assert got.shape == want.shape and maxabs(got, want) < 2e-5, (seed, clip, T, chunk, run.__name__)
+
+
+def test_mixing_the_two_step_protocols_inside_one_stream_is_refused():
+    """feed (DenBlock 2 in step) and feed_lagged (one step behind) on the same engine: only after clear()"""
+    net = make_netspec([16, 32, 64], 16, 4, 3, "relu6", 16)
+    st = seeded_state(bsvd_keys([16, 32, 64], 16, 4, 3, 16), 5)
+    ex = OracleExecutor(st)
+    eng = StreamEngine(net, ex, 8, 8, 4, chunk=1, alloc=lambda shape: torch.zeros(shape))
+    x = torch.zeros((1, 4, 8, 8))
+    eng.feed(x, (3, None))
+    with pytest.raises(RuntimeError, match="reset"):
+        eng.feed_lagged(x, (3, None))
+    eng.clear()
+    eng.feed_lagged(x, (3, None))
+    with pytest.raises(RuntimeError):
+        eng.feed(x, (3, None))
