@@ -56,6 +56,9 @@
 #ifndef BSVD_TUNE_NARROW_OCC
 #define BSVD_TUNE_NARROW_OCC 3     // waves/SIMD the 128-px x 32-ch wave tile is compiled for (3: 168 VGPRs + a 12-byte spill; 2: no spill)
 #endif
+#ifndef BSVD_TUNE_APFL
+#define BSVD_TUNE_APFL 1       // prefetch of the next tap's fragments into the SAME registers (see LITE): bit 0 the 128-accumulator tiles, bit 1 the narrow 64-channel tile, bit 2 the exit tile, bit 3 the stride-2 tiles
+#endif
 #ifndef BSVD_TUNE_APF
 #define BSVD_TUNE_APF 1        // split DBUF tiles that request the NEXT tap's pixel fragments in the middle of the current tap: 0 none, 1 the exit tile (NT == 1), 2 all, 3 fat tiles
 #endif
@@ -713,6 +716,32 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         if (BSVD_TUNE_PRIO == 2) __builtin_amdgcn_s_setprio(0);
         if (BSVD_TUNE_PRIO == 3) __builtin_amdgcn_s_setprio(2);
 
+        [[maybe_unused]] auto refill_single = [&](int cb, const ChunkSrc &cn) {      // single LDS buffer: after the chunk's barrier
+            if (cb + 1 < ncb) {        // single buffer: everybody is done reading it -> refill, publish
+                if constexpr (PAIRPF) {
+                    if ((cb + 1) & 1) {
+                        publish_hold(patch_buf);          // the odd chunk that came with chunk cb
+                        prefetch_pair(cb + 2);            // next line pair: one chunk period ahead of its first use
+                    } else {
+                        publish_even(patch_buf);
+                    }
+                } else if constexpr (REGPF) {
+                    publish_hold(patch_buf);
+                    prefetch_hold(cb + 2);
+                } else if constexpr (PAIR) {
+                    if ((cb + 1) & 1) {
+                        publish_hold(patch_buf);
+                    } else {
+                        fill_pair(cb + 1, patch_buf);
+                    }
+                } else if constexpr (FLAT) {
+                    fill_flat(cn, patch_buf);
+                } else {
+                    fill_patch(cn, patch_buf);
+                }
+            }
+            __syncthreads();
+        };
         const int nsteps = ncb * 9;
         int step = 0;
         // APF (A-operand prefetch): the plain loop below gives every tap one load phase (8 ds_read_b128 of the pixel fragments +
@@ -724,8 +753,13 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         // Measured r02 (interleaved A/B, ms per clip): fat 128-accumulator tile 20.05 -> 20.31 (SLOWER: its two waves per SIMD already
         // alternate load and MFMA phases, and the scheduling fences cost more than the exposed latency), 64-channel tile 6.33 =,
         // the 32-channel exit tile 0.63 -> 0.58.  Default: the exit tile only.
-        constexpr bool APF = PREC == 1 && C::DBUF && C::RING == 3 &&
-                             (BSVD_TUNE_APF == 2 || (BSVD_TUNE_APF == 1 && C::NT == 1) || (BSVD_TUNE_APF == 3 && C::MT * C::NT >= 8));
+        constexpr bool APF = PREC == 1 && (C::DBUF || ((BSVD_TUNE_APFL & 8) && C::STRIDE == 2)) && C::RING == 3 &&
+                             (((BSVD_TUNE_APFL & 8) && C::STRIDE == 2) || BSVD_TUNE_APF == 2 || (BSVD_TUNE_APF == 1 && C::NT == 1) || (BSVD_TUNE_APF == 3 && C::MT * C::NT >= 8) ||
+                              ((BSVD_TUNE_APFL & 1) && C::MT * C::NT >= 8));
+        // LITE: no second register set at all -- `lo` of tap k+1 is requested after pass 1 of tap k (as above), `hi` of tap k+1
+        // after pass 3 of tap k into the registers its MFMAs have just read; pass 1 of tap k+1 (8 MFMAs) covers that latency.
+        constexpr bool LITE = ((BSVD_TUNE_APFL & 1) && C::MT * C::NT >= 8) || ((BSVD_TUNE_APFL & 2) && C::MT == 4 && C::NT == 1) || ((BSVD_TUNE_APFL & 8) && C::STRIDE == 2) ||
+                              ((BSVD_TUNE_APFL & 4) && C::MT == 2 && C::NT == 1);
         if constexpr (APF) {
             auto load_hi = [&](const float *pc, int ky, int kx, f32x4 (&h)[C::MT]) {
 #pragma unroll
@@ -748,11 +782,11 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     // both patch buffers are free here (the barrier that ended chunk cb - 1): fill them with chunks cb, cb + 1
                     if ((cb & 1) == 0) { head_pair(cb >> 1); __syncthreads(); }
                 }
-                const float *pcur = patch_buf + (cb & 1) * C::PATCH_FLOATS;
-                float *pnext = patch_buf + ((cb + 1) & 1) * C::PATCH_FLOATS;
+                const float *pcur = patch_buf + (C::DBUF ? (cb & 1) * C::PATCH_FLOATS : 0);
+                [[maybe_unused]] float *pnext = patch_buf + (C::DBUF ? ((cb + 1) & 1) * C::PATCH_FLOATS : 0);
                 ChunkSrc cn = chunk_src(cb + 1 < ncb ? cb + 1 : cb);
                 if (cb + 1 >= ncb) cn.rs = make_rsrc(s.cur, 0u);
-                f32x4 s0[C::P], s1[C::P], s2[C::P];
+                [[maybe_unused]] f32x4 s0[C::P], s1[C::P], s2[C::P];
 #pragma unroll
                 for (int i = 0; i < C::P; ++i) s1[i] = s2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 f32x4 hiA[C::MT], hiB[C::MT], loA[C::MT], loB[C::MT];
@@ -761,21 +795,37 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
 #define BSVD_APF_TAP(T, HC, LC, HN, LN, BCUR, BFILL, SNEW, SOLD)                                                           \
                 {                                                                                                        \
                     load_b(step + 2 < nsteps ? step + 2 : nsteps - 1, BFILL);                                            \
-                    if constexpr (!HEADF) slice_load(cn, (T) * C::ROWS_PER_SLICE, SNEW);    /* rows >= PH: zeros */       \
+                    if constexpr (C::DBUF && !HEADF) slice_load(cn, (T) * C::ROWS_PER_SLICE, SNEW);    /* rows >= PH: zeros */ \
                     __builtin_amdgcn_sched_barrier(0);                                                                   \
                     pass(LC, BCUR, 0);                                                      /* hi(w) x lo(x) */           \
                     __builtin_amdgcn_sched_barrier(0);                                                                   \
                     if constexpr ((T) < 8) {                                                                             \
                         load_lo(pcur, ((T) + 1) / 3, ((T) + 1) % 3, LN);                                                 \
-                        load_hi(pcur, ((T) + 1) / 3, ((T) + 1) % 3, HN);                                                 \
+                        if constexpr (!LITE) load_hi(pcur, ((T) + 1) / 3, ((T) + 1) % 3, HN);                            \
                     }                                                                                                    \
                     __builtin_amdgcn_sched_barrier(0);                                      /* reads stay HERE: 16 MFMAs of cover */ \
                     pass(HC, BCUR, 1);                                                      /* lo(w) x hi(x) */           \
                     pass(HC, BCUR, 0);                                                      /* hi(w) x hi(x) */           \
-                    if constexpr (!HEADF)                                                                                \
+                    if constexpr (LITE && (T) < 8) {                                                                     \
+                        __builtin_amdgcn_sched_barrier(0);                                                               \
+                        load_hi(pcur, ((T) + 1) / 3, ((T) + 1) % 3, HN);                                                 \
+                        __builtin_amdgcn_sched_barrier(0);                                                               \
+                    }                                                                                                    \
+                    if constexpr (C::DBUF && !HEADF)                                                                     \
                         if ((T) >= BSVD_TUNE_D && (T) <= C::NSLICE - 1 + BSVD_TUNE_D) slice_store(pnext, ((T) - BSVD_TUNE_D) * C::ROWS_PER_SLICE, SOLD); \
                     ++step;                                                                                              \
                 }
+                if constexpr (LITE) {
+                    BSVD_APF_TAP(0, hiA, loA, hiA, loA, b0, b2, s0, S_OLD0)
+                    BSVD_APF_TAP(1, hiA, loA, hiA, loA, b1, b0, s1, S_OLD1)
+                    BSVD_APF_TAP(2, hiA, loA, hiA, loA, b2, b1, s2, S_OLD2)
+                    BSVD_APF_TAP(3, hiA, loA, hiA, loA, b0, b2, s0, S_OLD0)
+                    BSVD_APF_TAP(4, hiA, loA, hiA, loA, b1, b0, s1, S_OLD1)
+                    BSVD_APF_TAP(5, hiA, loA, hiA, loA, b2, b1, s2, S_OLD2)
+                    BSVD_APF_TAP(6, hiA, loA, hiA, loA, b0, b2, s0, S_OLD0)
+                    BSVD_APF_TAP(7, hiA, loA, hiA, loA, b1, b0, s1, S_OLD1)
+                    BSVD_APF_TAP(8, hiA, loA, hiA, loA, b2, b1, s2, S_OLD2)
+                } else {
                 BSVD_APF_TAP(0, hiA, loA, hiB, loB, b0, b2, s0, S_OLD0)
                 BSVD_APF_TAP(1, hiB, loB, hiA, loA, b1, b0, s1, S_OLD1)
                 BSVD_APF_TAP(2, hiA, loA, hiB, loB, b2, b1, s2, S_OLD2)
@@ -785,8 +835,10 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 BSVD_APF_TAP(6, hiA, loA, hiB, loB, b0, b2, s0, S_OLD0)
                 BSVD_APF_TAP(7, hiB, loB, hiA, loA, b1, b0, s1, S_OLD1)
                 BSVD_APF_TAP(8, hiA, loA, hiB, loB, b2, b1, s2, S_OLD2)
+                }
 #undef BSVD_APF_TAP
                 __syncthreads();
+                if constexpr (!C::DBUF) refill_single(cb, cn);
             }
         } else
         for (int cb = 0; cb < ncb; ++cb) {
@@ -836,32 +888,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
 #undef BSVD_TAP
             }
             __syncthreads();   // one barrier per 16-channel chunk (9 taps, 288 MFMAs per wave)
-            if constexpr (!C::DBUF) {
-                if (cb + 1 < ncb) {        // single buffer: everybody is done reading it -> refill, publish
-                    if constexpr (PAIRPF) {
-                        if ((cb + 1) & 1) {
-                            publish_hold(patch_buf);          // the odd chunk that came with chunk cb
-                            prefetch_pair(cb + 2);            // next line pair: one chunk period ahead of its first use
-                        } else {
-                            publish_even(patch_buf);
-                        }
-                    } else if constexpr (REGPF) {
-                        publish_hold(patch_buf);
-                        prefetch_hold(cb + 2);
-                    } else if constexpr (PAIR) {
-                        if ((cb + 1) & 1) {
-                            publish_hold(patch_buf);
-                        } else {
-                            fill_pair(cb + 1, patch_buf);
-                        }
-                    } else if constexpr (FLAT) {
-                        fill_flat(cn, patch_buf);
-                    } else {
-                        fill_patch(cn, patch_buf);
-                    }
-                }
-                __syncthreads();
-            }
+            if constexpr (!C::DBUF) refill_single(cb, cn);
         }
     } else {
         // ============================================================================= GENERIC path
