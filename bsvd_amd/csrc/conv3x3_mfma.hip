@@ -56,6 +56,12 @@
 #ifndef BSVD_TUNE_NARROW_OCC
 #define BSVD_TUNE_NARROW_OCC 3     // waves/SIMD the 128-px x 32-ch wave tile is compiled for (3: 168 VGPRs + a 12-byte spill; 2: no spill)
 #endif
+#ifndef BSVD_TUNE_SKIP_DEAD
+#define BSVD_TUNE_SKIP_DEAD 1  // 128-accumulator (LITE) tiles: waves entirely below the image issue no fragment reads / MFMAs
+#endif
+#ifndef BSVD_TUNE_EPI_PIPE
+#define BSVD_TUNE_EPI_PIPE 0   // split epilogue: tile k+1 staged into the transposition scratch behind the reads of tile k, no waits in between
+#endif
 #ifndef BSVD_TUNE_APFL
 #define BSVD_TUNE_APFL 1       // prefetch of the next tap's fragments into the SAME registers (see LITE): bit 0 the 128-accumulator tiles, bit 1 the narrow 64-channel tile, bit 2 the exit tile, bit 3 the stride-2 tiles
 #endif
@@ -777,6 +783,19 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bv[nt][bpart]),
                                                                              __builtin_bit_cast(f16x8, av[mt]), acc[mt][nt], 0, 0, 0);
             };
+            // A wave whose 2*MT output rows all lie below the image (135-row layers: the lower half of the last 16-row tile) runs
+            // its own loop: it stages its share of every chunk and meets the chunk barriers, but reads no fragments and issues
+            // no MFMAs.  (Guarding the reads / MFMAs of the common loop with a wave-uniform branch instead cost every wave its
+            // cross-tap schedule: 19.49 -> 19.83 ms per C1 clip.)
+            const bool wlive = (BSVD_TUNE_SKIP_DEAD && LITE) ? oy0 + 2 * C::MT * wm < p.Ho : true;
+            if (!wlive) {
+                for (int cb = 0; cb < ncb; ++cb) {
+                    ChunkSrc cn = chunk_src(cb + 1 < ncb ? cb + 1 : cb);
+                    if (cb + 1 >= ncb) cn.rs = make_rsrc(s.cur, 0u);
+                    fill_patch(cn, patch_buf + ((cb + 1) & 1) * C::PATCH_FLOATS);
+                    __syncthreads();
+                }
+            } else
             for (int cb = 0; cb < ncb; ++cb) {
                 if constexpr (HEADF) {
                     // both patch buffers are free here (the barrier that ended chunk cb - 1): fill them with chunks cb, cb + 1
@@ -945,6 +964,12 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
     }
 
     TL(2);
+    if constexpr (BSVD_TUNE_SKIP_DEAD && FAST && PREC == 1 && (BSVD_TUNE_APFL & 1) && C::MT * C::NT >= 8 && C::DBUF && C::RING == 3) {
+        // a wave entirely below the image (see wlive in the K loop) has nothing to store; no workgroup barrier follows
+#ifndef BSVD_TIMELINE
+        if (oy0 + 2 * C::MT * wm >= p.Ho) return;
+#endif
+    }
     if (BSVD_TUNE_PRIO == 1 || BSVD_TUNE_PRIO == 2) __builtin_amdgcn_s_setprio(2);
     if (BSVD_TUNE_PRIO == 3) __builtin_amdgcn_s_setprio(0);
     // ---- epilogue.  Lane (li, lh) holds pixel li of the 2 x 16 pixel block of MFMA tile mt (row li>>4, column li&15)
@@ -1117,6 +1142,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         };
         constexpr int NITEM = C::MT * C::NT * 2;
         f32x4 ecur[2], enxt[2];
+        [[maybe_unused]] f32x4 pv[2][2];
         if constexpr (EPI == BSVD_EPI_PS_ADD) skip_load(item_of(0), ecur);
 #pragma unroll
         for (int i = 0; i < NITEM; ++i) {
@@ -1125,17 +1151,39 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 if (i + 1 < NITEM) skip_load(item_of(i + 1), enxt);
             float v[8];
             if constexpr (PREC == 1) {
-                if (sidx == 0) {             // stage this (mt, nt) tile: row = pixel li, 8 consecutive channels per write
+                // The transposition scratch is wave-private and a wave's LDS instructions execute in program order, so neither the
+                // reads after the staging writes nor the next tile's writes after these reads need a wait: EPI_PIPE requests both
+                // items of tile k, then stages tile k+1 behind them, and only then converts -- the LDS round trips of a tile sit
+                // under the previous tile's conversion instead of in front of every item.
+                auto stage = [&](int smt, int snt) {      // row = pixel li, 8 consecutive channels per write
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         float *w = sc + li * 36 + 8 * (2 * h + lh);
-                        const f32x16 &a = acc[mt][nt];
+                        const f32x16 &a = acc[smt][snt];
                         *reinterpret_cast<f32x4 *>(w) = f32x4{a[8 * h], a[8 * h + 1], a[8 * h + 2], a[8 * h + 3]};
                         *reinterpret_cast<f32x4 *>(w + 4) = f32x4{a[8 * h + 4], a[8 * h + 5], a[8 * h + 6], a[8 * h + 7]};
                     }
                     __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");
+                };
+                if constexpr (BSVD_TUNE_EPI_PIPE) {
+                    if (sidx == 0) {
+                        if (i == 0) stage(mt, nt);
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const int m2 = (lane + 64 * s2) >> 2;
+                            pv[s2][0] = *reinterpret_cast<const f32x4 *>(sc + m2 * 36 + q * 8);
+                            pv[s2][1] = *reinterpret_cast<const f32x4 *>(sc + m2 * 36 + q * 8 + 4);
+                        }
+                        if (i + 2 < NITEM) stage(((i + 2) >> 1) / C::NT, ((i + 2) >> 1) % C::NT);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = pv[sidx][0][j] + bq[nt][0][0][j]; v[4 + j] = pv[sidx][1][j] + bq[nt][0][1][j]; }
+                } else {
+                if (sidx == 0) {
+                    stage(mt, nt);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
                 const int m = (lane + 64 * sidx) >> 2;
@@ -1143,6 +1191,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 const f32x4 v1 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8 + 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v[j] = v0[j] + bq[nt][0][0][j]; v[4 + j] = v1[j] + bq[nt][0][1][j]; }
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = acc[mt][nt][8 * sidx + j] + bq[nt][sidx][j >> 2][j & 3];
