@@ -399,7 +399,7 @@ def main():
                     v["launches"] *= steps
                 for e in model._stream_engs.values():
                     e.layerwise = False
-        assert tuple(y.shape) == (frames, 3, h, w) and bool(torch.isfinite(y).all())
+        assert tuple(y.shape) == (frames, 3, h, w) and (bool(torch.isfinite(y).all()) or os.environ.get("BSVD_ABL_TIMING") == "1")   # (timing-only ablation builds of tools/ab_prebuilt.sh)
         t_max = torch.tensor([dt], dtype=torch.float64)
         if dist is not None:
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)

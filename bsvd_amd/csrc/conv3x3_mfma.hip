@@ -56,11 +56,14 @@
 #ifndef BSVD_TUNE_NARROW_OCC
 #define BSVD_TUNE_NARROW_OCC 3     // waves/SIMD the 128-px x 32-ch wave tile is compiled for (3: 168 VGPRs + a 12-byte spill; 2: no spill)
 #endif
+#ifndef BSVD_ABL
+#define BSVD_ABL 0             // TIMING-ONLY ablations of the prefetching K loop (results are wrong): 1 no chunk barrier, 2 no patch slices, 4 no weight loads, 8 half the weight loads (lo := hi), 16 all weight loads from two L1-resident slabs
+#endif
+#ifndef BSVD_TUNE_PASS_ORDER
+#define BSVD_TUNE_PASS_ORDER 0 // MFMA order inside a pass of the prefetching loops: 0 pixel-tile major, 1 channel-tile major
+#endif
 #ifndef BSVD_TUNE_SKIP_DEAD
 #define BSVD_TUNE_SKIP_DEAD 1  // 128-accumulator (LITE) tiles: waves entirely below the image issue no fragment reads / MFMAs
-#endif
-#ifndef BSVD_TUNE_EPI_PIPE
-#define BSVD_TUNE_EPI_PIPE 0   // split epilogue: tile k+1 staged into the transposition scratch behind the reads of tile k, no waits in between
 #endif
 #ifndef BSVD_TUNE_APFL
 #define BSVD_TUNE_APFL 1       // prefetch of the next tap's fragments into the SAME registers (see LITE): bit 0 the 128-accumulator tiles, bit 1 the narrow 64-channel tile, bit 2 the exit tile, bit 3 the stride-2 tiles
@@ -244,6 +247,13 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
 {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+#ifndef BSVD_TUNE_SLICE_AUX
+#define BSVD_TUNE_SLICE_AUX 0   // cache policy of the activation (patch slice) loads: 0 default, 2 nt (streamed: every line is read once per tile)
+#endif
+__device__ __forceinline__ f32x4 buf_load4_act(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, BSVD_TUNE_SLICE_AUX));
+}
 
 struct ChunkSrc {          // wave-uniform description of one 16-channel chunk's source
     __amdgpu_buffer_rsrc_t rs;
@@ -314,6 +324,19 @@ __device__ __forceinline__ void tl_stamp(int slot, int k)
 #define TL(k) tl_stamp(blockIdx.x, k)
 #else
 #define TL(k)
+#endif
+#if defined(BSVD_TIMELINE) && BSVD_TIMELINE == 2
+// epilogue phase split (shader cycles of wave 0, summed over the items): slot 5 staging writes + wait, 6 scratch reads + wait,
+// 7 bias/activation/split + store issue.  The stamps serialise the phases: read the proportions, not the total.
+#define TLP_BEGIN() unsigned long long tlp_t = __builtin_amdgcn_s_memtime()
+#define TLP_MARK(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tlp_acc[k] += n_ - tlp_t; tlp_t = n_; }
+#define TLP_WAIT_MARK(k, a, b) { asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(a), "v"(b) : "memory"); TLP_MARK(k) }
+#define TLP_FLUSH() if (threadIdx.x == 0 && blockIdx.x < BSVD_TIMELINE_SLOTS) { g_timeline[blockIdx.x][5] = tlp_acc[0]; g_timeline[blockIdx.x][6] = tlp_acc[1]; g_timeline[blockIdx.x][7] = tlp_acc[2]; }
+#else
+#define TLP_BEGIN()
+#define TLP_MARK(k)
+#define TLP_WAIT_MARK(k, a, b)
+#define TLP_FLUSH()
 #endif
 // HEADF (fused network entry, BsvdConvArgs.head_w_packed): p.x is the caller's planar fp32 input; the tile computes the
 // first conv's output (head_cin -> Cin channels, act, zero outside the image) on its own 18 x 18 patch with MFMAs
@@ -454,11 +477,12 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         for (int nt = 0; nt < C::NT; ++nt)
             vb[nt] = nb0 + 32 * nt < p.Cout ? (unsigned)(lh * p.Cout + nb0 + 32 * nt) * 16u : BSVD_OOB;
         auto load_b = [&](int step, f32x4 (&b)[C::NT][2]) {
-            const unsigned so = (unsigned)step * slab_bytes;
+            const unsigned so = (BSVD_ABL & 16) ? (unsigned)(step & 1) * slab_bytes : (unsigned)step * slab_bytes;   // 16: timing only, L1-resident weights
 #pragma unroll
             for (int nt = 0; nt < C::NT; ++nt) {
                 b[nt][0] = buf_load4(rs_w, vb[nt], so);
-                b[nt][1] = buf_load4(rs_w, vb[nt], so + g_bytes);
+                if constexpr (BSVD_ABL & 8) b[nt][1] = b[nt][0];      // timing only: half the weight stream, realistic operands
+                else b[nt][1] = buf_load4(rs_w, vb[nt], so + g_bytes);
             }
         };
 
@@ -495,7 +519,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     }
                 }
                 const unsigned voff = ok ? (unsigned)(gy * p.W + gx) * c.ps4 + pq * 16u : BSVD_OOB;
-                v[i] = buf_load4(c.rs, voff, c.soff);
+                v[i] = buf_load4_act(c.rs, voff, c.soff);
             }
         };
         auto slice_store = [&](float *pb, int row0, const f32x4 (&v)[C::P]) {
@@ -511,6 +535,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         f32x4 b0[C::NT][2], b1[C::NT][2], b2[C::NT][2];
         load_b(0, b0);
         if constexpr (C::RING == 3) load_b(1, b1);
+        if constexpr ((BSVD_ABL & 4) != 0) load_b(2, b2);     // (timing only: the ring keeps these three slabs for the whole tile)
         // whole patch in flight at once, then published: one HBM latency per tile instead of one per slice
         auto fill_patch = [&](const ChunkSrc &c, float *pb) {
             // G slices in flight at once, then published.  Everything at once where the registers are there (prologue of
@@ -776,6 +801,15 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 for (int mt = 0; mt < C::MT; ++mt) l[mt] = *reinterpret_cast<const f32x4 *>(a_ptr(pc, ky, kx, mt, 1));
             };
             auto pass = [&](const f32x4 (&av)[C::MT], const f32x4 (&bv)[C::NT][2], int bpart) {
+                if constexpr (BSVD_TUNE_PASS_ORDER == 1) {      // weight operand held across consecutive MFMAs instead of the pixel operand
+#pragma unroll
+                    for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < C::MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bv[nt][bpart]),
+                                                                                 __builtin_bit_cast(f16x8, av[mt]), acc[mt][nt], 0, 0, 0);
+                    return;
+                }
 #pragma unroll
                 for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
@@ -813,8 +847,8 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 load_lo(pcur, 0, 0, loA);
 #define BSVD_APF_TAP(T, HC, LC, HN, LN, BCUR, BFILL, SNEW, SOLD)                                                           \
                 {                                                                                                        \
-                    load_b(step + 2 < nsteps ? step + 2 : nsteps - 1, BFILL);                                            \
-                    if constexpr (C::DBUF && !HEADF) slice_load(cn, (T) * C::ROWS_PER_SLICE, SNEW);    /* rows >= PH: zeros */ \
+                    if constexpr (!(BSVD_ABL & 4)) load_b(step + 2 < nsteps ? step + 2 : nsteps - 1, BFILL);             \
+                    if constexpr (C::DBUF && !HEADF && !(BSVD_ABL & 2)) slice_load(cn, (T) * C::ROWS_PER_SLICE, SNEW);    /* rows >= PH: zeros */ \
                     __builtin_amdgcn_sched_barrier(0);                                                                   \
                     pass(LC, BCUR, 0);                                                      /* hi(w) x lo(x) */           \
                     __builtin_amdgcn_sched_barrier(0);                                                                   \
@@ -830,7 +864,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                         load_hi(pcur, ((T) + 1) / 3, ((T) + 1) % 3, HN);                                                 \
                         __builtin_amdgcn_sched_barrier(0);                                                               \
                     }                                                                                                    \
-                    if constexpr (C::DBUF && !HEADF)                                                                     \
+                    if constexpr (C::DBUF && !HEADF && !(BSVD_ABL & 2))                                                  \
                         if ((T) >= BSVD_TUNE_D && (T) <= C::NSLICE - 1 + BSVD_TUNE_D) slice_store(pnext, ((T) - BSVD_TUNE_D) * C::ROWS_PER_SLICE, SOLD); \
                     ++step;                                                                                              \
                 }
@@ -856,7 +890,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 BSVD_APF_TAP(8, hiA, loA, hiB, loB, b2, b1, s2, S_OLD2)
                 }
 #undef BSVD_APF_TAP
-                __syncthreads();
+                if constexpr (!(BSVD_ABL & 1)) __syncthreads();
                 if constexpr (!C::DBUF) refill_single(cb, cn);
             }
         } else
@@ -1142,7 +1176,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         };
         constexpr int NITEM = C::MT * C::NT * 2;
         f32x4 ecur[2], enxt[2];
-        [[maybe_unused]] f32x4 pv[2][2];
+        [[maybe_unused]] unsigned long long tlp_acc[3] = {0, 0, 0};
         if constexpr (EPI == BSVD_EPI_PS_ADD) skip_load(item_of(0), ecur);
 #pragma unroll
         for (int i = 0; i < NITEM; ++i) {
@@ -1150,11 +1184,11 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
             if constexpr (EPI == BSVD_EPI_PS_ADD)
                 if (i + 1 < NITEM) skip_load(item_of(i + 1), enxt);
             float v[8];
+            TLP_BEGIN();
             if constexpr (PREC == 1) {
-                // The transposition scratch is wave-private and a wave's LDS instructions execute in program order, so neither the
-                // reads after the staging writes nor the next tile's writes after these reads need a wait: EPI_PIPE requests both
-                // items of tile k, then stages tile k+1 behind them, and only then converts -- the LDS round trips of a tile sit
-                // under the previous tile's conversion instead of in front of every item.
+                // (r03: requesting both items of tile k, staging tile k+1 behind those reads with no wait in between -- a wave's LDS
+                //  instructions execute in order -- and only then converting moved nothing, 19.65 vs 19.67 ms: the timeline build
+                //  (tools/timeline.py, -DBSVD_TIMELINE=2) puts 80 % of the epilogue into the convert + store part, 20 % into LDS.)
                 auto stage = [&](int smt, int snt) {      // row = pixel li, 8 consecutive channels per write
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("" ::: "memory");
@@ -1168,30 +1202,17 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("" ::: "memory");
                 };
-                if constexpr (BSVD_TUNE_EPI_PIPE) {
-                    if (sidx == 0) {
-                        if (i == 0) stage(mt, nt);
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            const int m2 = (lane + 64 * s2) >> 2;
-                            pv[s2][0] = *reinterpret_cast<const f32x4 *>(sc + m2 * 36 + q * 8);
-                            pv[s2][1] = *reinterpret_cast<const f32x4 *>(sc + m2 * 36 + q * 8 + 4);
-                        }
-                        if (i + 2 < NITEM) stage(((i + 2) >> 1) / C::NT, ((i + 2) >> 1) % C::NT);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j] = pv[sidx][0][j] + bq[nt][0][0][j]; v[4 + j] = pv[sidx][1][j] + bq[nt][0][1][j]; }
-                } else {
                 if (sidx == 0) {
                     stage(mt, nt);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
+                TLP_MARK(0);
                 const int m = (lane + 64 * sidx) >> 2;
                 const f32x4 v0 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8);
                 const f32x4 v1 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8 + 4);
+                TLP_WAIT_MARK(1, v0, v1);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v[j] = v0[j] + bq[nt][0][0][j]; v[4 + j] = v1[j] + bq[nt][0][1][j]; }
-                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = acc[mt][nt][8 * sidx + j] + bq[nt][sidx][j >> 2][j & 3];
@@ -1250,9 +1271,13 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 }
             }
             if constexpr (EPI == BSVD_EPI_PS_ADD) { ecur[0] = enxt[0]; ecur[1] = enxt[1]; }
+            TLP_MARK(2);
+#if !defined(BSVD_TIMELINE) || BSVD_TIMELINE != 2
             if (i == 0) TL(5);
             if (i == NITEM / 2 - 1) TL(6);
+#endif
         }
+        TLP_FLUSH();
     };
     using std::integral_constant;
     auto with_act = [&](auto epi_c, auto psf_c) {

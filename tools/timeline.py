@@ -53,9 +53,16 @@ def main():
     us = (t[:, :4] - t0) / 100.0                       # s_memrealtime ticks at 100 MHz
     pro, loop, epi = us[:, 1] - us[:, 0], us[:, 2] - us[:, 1], us[:, 3] - us[:, 2]
     print("%d workgroups, launch span %.1f us" % (len(us), us[:, 3].max()))
-    e1 = (t[:, 5] - t0) / 100.0 - us[:, 2]; e2 = (t[:, 6] - t0) / 100.0 - us[:, 2]
-    print("  inside the epilogue: first item done after %.2f us, half of the items after %.2f us, all after %.2f us (means)"
-          % (e1.mean(), e2.mean(), (us[:, 3] - us[:, 2]).mean()))
+    if os.environ.get("TL_PHASES"):                    # -DBSVD_TIMELINE=2 build: slots 5..7 = shader cycles per epilogue phase
+        ph = t[:, 5:8].astype(np.float64)
+        tot = ph.sum(axis=1)
+        print("  epilogue phases of wave 0 (shader cycles, mean): staging writes+wait %.0f, scratch reads+wait %.0f, convert+store issue %.0f"
+              "  (= %.2f / %.2f / %.2f of their sum)" % (ph[:, 0].mean(), ph[:, 1].mean(), ph[:, 2].mean(),
+                                                         *(ph / tot[:, None]).mean(axis=0)))
+    else:
+        e1 = (t[:, 5] - t0) / 100.0 - us[:, 2]; e2 = (t[:, 6] - t0) / 100.0 - us[:, 2]
+        print("  inside the epilogue: first item done after %.2f us, half of the items after %.2f us, all after %.2f us (means)"
+              % (e1.mean(), e2.mean(), (us[:, 3] - us[:, 2]).mean()))
     for name, v in (("prologue", pro), ("K loop", loop), ("epilogue", epi), ("whole tile", us[:, 3] - us[:, 0])):
         print("  %-10s mean %7.2f us   p10 %7.2f   p50 %7.2f   p90 %7.2f" % (name, v.mean(), np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90)))
     hw = t[:, 4]
