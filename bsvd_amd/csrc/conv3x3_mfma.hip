@@ -57,7 +57,7 @@
 #define BSVD_TUNE_NARROW_OCC 3     // waves/SIMD the 128-px x 32-ch wave tile is compiled for (3: 168 VGPRs + a 12-byte spill; 2: no spill)
 #endif
 #ifndef BSVD_ABL
-#define BSVD_ABL 0             // TIMING-ONLY ablations of the prefetching K loop (results are wrong): 1 no chunk barrier, 2 no patch slices, 4 no weight loads, 8 half the weight loads (lo := hi), 16 all weight loads from two L1-resident slabs
+#define BSVD_ABL 0             // TIMING-ONLY ablations of the prefetching K loop (results are wrong): 1 no chunk barrier, 2 no patch slices, 4 no weight loads, 8 half the weight loads (lo := hi), 16 all weight loads from two L1-resident slabs, 32 split epilogue without its stores, 64 split epilogue without the conversion, 128 split epilogue storing lane-contiguous 2-KB runs
 #endif
 #ifndef BSVD_TUNE_PASS_ORDER
 #define BSVD_TUNE_PASS_ORDER 0 // MFMA order inside a pass of the prefetching loops: 0 pixel-tile major, 1 channel-tile major
@@ -1257,6 +1257,14 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                         hi[j] = (_Float16)vs;
                         lo[j] = lo_keep((_Float16)__builtin_fmaf((float)hi[j], -1.0f, vs));
                     }
+                    if constexpr ((BSVD_ABL & 32) != 0) {      // timing only: conversion kept alive, stores never executed
+                        if (p.Cout < 0) { *reinterpret_cast<f32x4 *>(dst) = __builtin_bit_cast(f32x4, hi); *reinterpret_cast<f32x4 *>(dst + 8) = __builtin_bit_cast(f32x4, lo); }
+                    } else if constexpr ((BSVD_ABL & 128) != 0) {  // timing only: the same bytes as fully coalesced 2-KB runs per wave and item
+                        float *d2 = p.y + (int64_t)f * 0 + ((int64_t)((blockIdx.x % (gridDim.x - gridDim.x / 16)) * 4 + wid) * NITEM + i) * 512 + lane * 8;   // (stays inside the tensor: edge tiles fold back)
+                        *reinterpret_cast<f32x4 *>(d2) = __builtin_bit_cast(f32x4, hi); *reinterpret_cast<f32x4 *>(d2 + 4) = __builtin_bit_cast(f32x4, lo);
+                    } else if constexpr ((BSVD_ABL & 64) != 0) {   // timing only: stores kept, no split conversion
+                        *reinterpret_cast<f32x4 *>(dst) = f32x4{v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4 *>(dst + 8) = f32x4{v[4], v[5], v[6], v[7]};
+                    } else {
 #if BSVD_TUNE_NT_STORE
                     __builtin_nontemporal_store(__builtin_bit_cast(f32x4, hi), reinterpret_cast<f32x4 *>(dst));
                     __builtin_nontemporal_store(__builtin_bit_cast(f32x4, lo), reinterpret_cast<f32x4 *>(dst + 8));
@@ -1264,6 +1272,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     *reinterpret_cast<f32x4 *>(dst) = __builtin_bit_cast(f32x4, hi);
                     *reinterpret_cast<f32x4 *>(dst + 8) = __builtin_bit_cast(f32x4, lo);
 #endif
+                    }
                 } else {
                     float *dst = t.dst;
                     *reinterpret_cast<f32x4 *>(dst) = f32x4{v[0], v[1], v[2], v[3]};
