@@ -107,6 +107,40 @@ def test_layer_split_vs_oracle(cin, cout, stride, tsm, act, epi, T, H, W):
         assert err < TIGHT
 
 
+FAT_CASES = [
+    # >= 800 workgroups of the 256-px x 128-ch tile, image height = 8 (mod 16): the lower wave pair of the last tile row lies entirely
+    # below the image and runs the staging-only loop (conv3x3_mfma.hip, `wlive`)
+    (128, 128, True, "relu6", 0, 2, 24, 3200),
+    (128, 256, False, "none", 1, 1, 40, 2160),
+]
+
+
+@pytest.mark.parametrize("cin,cout,tsm,act,epi,T,H,W", FAT_CASES)
+def test_fat_tile_with_waves_below_the_image(cin, cout, tsm, act, epi, T, H, W):
+    from bsvd_amd.netspec import ConvSpec
+    rs = np.random.RandomState(H + W)
+    sp = ConvSpec("l", "l", cin, cout, 1, tsm, act, epi)
+    st = seeded_state([("e0.weight", (16, 4, 3, 3)), ("e0.bias", (16,)), ("l.weight", (cout, cin, 3, 3)),
+                       ("l.bias", (cout,)), ("e1.weight", (3, 16, 3, 3)), ("e1.bias", (3,))], 11)
+    gex, oex = _exec(_Net(sp), st), OracleExecutor(st, double=True)
+    x = torch.from_numpy(rs.standard_normal((T, H, W, cin)).astype(np.float32))
+    extra = extra_dev = None
+    eps = 0
+    if epi == 1:
+        extra = from_split(to_split(torch.from_numpy(rs.standard_normal((T, 2 * H, 2 * W, cout // 4)).astype(np.float32))))
+        extra_dev, eps = to_split(extra).to(_dev()), cout // 4
+    xq = from_split(to_split(x))
+    want = oex.conv(sp, xq, None, None, extra, eps, 1)
+    gex.record_variants = True
+    got = from_split(gex.conv(sp, to_split(x).to(_dev()), None, None, extra_dev, eps, 1).cpu())
+    assert "<4,2,2,2,1>[f16x3]" in gex.last_variant, gex.last_variant
+    err = maxabs(got.numpy(), want.numpy())
+    print("fat layer %s max-abs %.3e (|y| max %.1f)" % ((cin, cout, tsm, epi, H, W), err, float(want.abs().max())))
+    assert err < TIGHT
+    # the rows next to the dead half tile, separately (a wrong barrier count or a skipped store would show here first)
+    assert maxabs(got.numpy()[:, -8:], want.numpy()[:, -8:]) < TIGHT
+
+
 def _module(st, mode="clip"):
     import bsvd_amd
     m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, in_ch=4, out_ch=3, norm="none", act="relu6", interm_ch=64,
