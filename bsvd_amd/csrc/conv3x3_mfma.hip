@@ -62,6 +62,9 @@
 #ifndef BSVD_TUNE_PASS_ORDER
 #define BSVD_TUNE_PASS_ORDER 0 // MFMA order inside a pass of the prefetching loops: 0 pixel-tile major, 1 channel-tile major
 #endif
+#ifndef BSVD_TUNE_ZSKIP
+#define BSVD_TUNE_ZSKIP 1      // 128-accumulator split tiles leave the all-zero temporal-shift chunks of a clip's first / last frame out of the K loop
+#endif
 #ifndef BSVD_TUNE_SKIP_DEAD
 #define BSVD_TUNE_SKIP_DEAD 1  // 128-accumulator (LITE) tiles: waves entirely below the image issue no fragment reads / MFMAs
 #endif
@@ -378,7 +381,25 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
     if (f + 1 < p.frames) { s.next = s.cur + p.x_fs; s.next_ps = p.Cin; s.next_co = 0; }
     else                  { s.next = p.halo_next; s.next_ps = p.halo_next_ps; s.next_co = p.halo_next_co; }
 
-    const int ncb = p.Cin >> 4;
+    // 16-channel chunks of K.  ZSKIP (128-accumulator split tiles): a temporal-shift group whose source frame does not exist -- the
+    // `next` group of a clip's / stream's last frame, the `prev` group of its first one (bsvd_arch.py:94,104 feeds zeros there) --
+    // is all zeros, so its chunks are left out of the K loop: chunk_src / load_b below take LIVE chunk / step indices and map
+    // them (i -> i + zs_a, then + zs_c from zs_b on).  Adding exact zero products leaves an fp32 accumulator bit for bit as it
+    // was, so the output is identical; a 10-frame clip saves 2/10 x 1/8 of the MFMAs of its 16 temporal-fusion layers.
+    constexpr bool ZSKIP = BSVD_TUNE_ZSKIP && FAST && PREC == 1 && !MIXF && !HEADF && C::DBUF && C::RING == 3 && C::STRIDE == 1 &&
+                           (BSVD_TUNE_APFL & 1) && C::MT * C::NT >= 8;
+    int ncb = p.Cin >> 4;
+    [[maybe_unused]] int zs_a = 0, zs_b = 0, zs_c = 0;
+    if constexpr (ZSKIP) {
+        const int f16 = p.fold >> 4;
+        if (f16 > 0 && (p.fold & 15) == 0) {
+            zs_b = f16;
+            if (s.next == nullptr) zs_a = f16;
+            if (s.prev == nullptr) zs_c = f16;
+            zs_b -= zs_a;                       // in live indices: the prev group starts after the live next-group chunks
+            ncb -= zs_a + zs_c;
+        }
+    }
 
     // A fragments: per-lane offset into the LDS patch (floats)
     const int a_lane = C::lds_off((2 * C::MT * wm + (li >> 4)) * C::STRIDE, (li & 15) * C::STRIDE, lh);
@@ -449,6 +470,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         auto chunk_src = [&](int cb) {
             ChunkSrc c;
             c.mixed = false;
+            if constexpr (ZSKIP) cb = cb + zs_a + (cb >= zs_b ? zs_c : 0);
             const int c0 = cb * 16;
             if constexpr (MIX) {
                 if (p.fold == 8 && cb == 0) {
@@ -477,6 +499,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         for (int nt = 0; nt < C::NT; ++nt)
             vb[nt] = nb0 + 32 * nt < p.Cout ? (unsigned)(lh * p.Cout + nb0 + 32 * nt) * 16u : BSVD_OOB;
         auto load_b = [&](int step, f32x4 (&b)[C::NT][2]) {
+            if constexpr (ZSKIP) step = step + 9 * zs_a + (step >= 9 * zs_b ? 9 * zs_c : 0);
             const unsigned so = (BSVD_ABL & 16) ? (unsigned)(step & 1) * slab_bytes : (unsigned)step * slab_bytes;   // 16: timing only, L1-resident weights
 #pragma unroll
             for (int nt = 0; nt < C::NT; ++nt) {

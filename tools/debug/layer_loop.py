@@ -1,7 +1,7 @@
 """One conv layer, realistic operands (seeded weights, ReLU6-ranged split16 input produced by a real layer), launched back to back for a few
 seconds (sustained: the power cap applies): ms per launch.  For attributing costs with the timing-only ablation builds (BSVD_HIP_LIB=...,
 -DBSVD_ABL=...): the layer's INPUT stays realistic whatever the ablated kernel writes.
-usage: BSVD_HIP_LIB=... python tools/debug/layer_loop.py [Cin=128] [Cout=128] [H=270] [W=480] [frames=10] [seconds=3] [stride=1]"""
+usage: BSVD_HIP_LIB=... python tools/debug/layer_loop.py [Cin=128] [Cout=128] [H=270] [W=480] [frames=10] [seconds=3] [stride=1] [tsm=0]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -13,6 +13,7 @@ a = [int(v) for v in sys.argv[1:6]]
 cin, cout, H, W, T = (a + [128, 128, 270, 480, 10][len(a):])
 secs = float(sys.argv[6]) if len(sys.argv) > 6 else 3.0
 stride = int(sys.argv[7]) if len(sys.argv) > 7 else 1
+tsm = bool(int(sys.argv[8])) if len(sys.argv) > 8 else False
 dev = torch.device("cuda", 0)
 rs = np.random.RandomState(0)
 
@@ -22,7 +23,7 @@ class Net:
 
 
 pre = ConvSpec("pre", "pre", 4, cin, 1, False, "relu6", 0)
-sp = ConvSpec("l", "l", cin, cout, stride, False, "relu6", 0)
+sp = ConvSpec("l", "l", cin, cout, stride, tsm, "relu6", 0)
 net = Net(); net.layers = [pre, sp]
 st = {}
 for s in net.layers:
