@@ -103,3 +103,17 @@ def test_random_streams_on_rings_and_graphs(seed):
         m.reset()
         assert torch.equal(torch.cat([o for o in outs if o is not None]), want)
     m.release_stream_buffers()
+
+
+def test_random_layers_forced_onto_the_128_accumulator_tile():
+    """tests/fat_tile_fuzz_driver.py in a fresh interpreter with BSVD_FAT_MIN_WGS=1: the fat tile's prefetching K loop, its staging-only
+    loop for waves below the image and its zero-chunk skip on 24 small random geometries vs the double-accumulating oracle."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, BSVD_FAT_MIN_WGS="1", PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, os.path.join(here, "fat_tile_fuzz_driver.py"), "24"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0 and "FUZZ OK 24" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
