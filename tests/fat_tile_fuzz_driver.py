@@ -28,7 +28,19 @@ def draw(rs):
     return cin, cout, 1, tsm, act, epi, T, H, W
 
 
+def nets(n):
+    """whole bsvd_c64 / c32-sized networks on small random clips with every wide layer on the fat tile: clip vs the oracle in both
+    precisions, stream schedule bit-identical (tests/test_gpu_fuzz.py::test_random_clip_whole_network under the override)"""
+    import test_gpu_fuzz as F
+    for seed in range(n):
+        print("net case", seed, flush=True)
+        F.test_random_clip_whole_network(seed)
+    print("FUZZ NETS OK", n)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[2] == "nets":
+        return nets(int(sys.argv[1]))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     import torch
     from bsvd_amd.engine import HipExecutor

@@ -117,3 +117,16 @@ def test_random_layers_forced_onto_the_128_accumulator_tile():
                        timeout=900)
     print(r.stdout[-3000:])
     assert r.returncode == 0 and "FUZZ OK 24" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_random_networks_with_the_wide_layers_forced_onto_the_128_accumulator_tile():
+    """... and six whole networks (clip vs oracle in both precisions, stream == clip bit for bit) under the same override."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, BSVD_FAT_MIN_WGS="1", PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, os.path.join(here, "fat_tile_fuzz_driver.py"), "6", "nets"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0 and "FUZZ NETS OK 6" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
