@@ -221,6 +221,53 @@ def cpu_baseline(model, h, w, blind, frames=10):
                       "1 warm-up + best of 2; host CPU: %s" % (frames, 3 if blind else 4, h, w, cpu)}
 
 
+def power_probe(step, seconds):
+    """rocm-smi package power / shader clock while `step` loops (untimed, after the timed region, N = 1 only): the split mode runs at
+    the package power cap with the clock throttled, and the line should say so itself.  None if rocm-smi is
+    absent or prints something else."""
+    import re
+    import subprocess
+    import threading
+    import torch
+    rows, stop = [], threading.Event()
+
+    def smi(*flags):
+        return subprocess.run(["rocm-smi", *flags], capture_output=True, text=True, timeout=10).stdout
+
+    def sample():
+        while not stop.is_set():
+            try:
+                out = smi("--showpower", "--showclocks")
+                pw = re.search(r"GPU\[0\].*?Package Power \(W\):\s*([0-9.]+)", out)
+                ck = re.search(r"GPU\[0\].*?sclk clock level:.*?\((\d+)Mhz\)", out)
+                if pw and ck:
+                    rows.append((float(pw.group(1)), float(ck.group(1))))
+            except Exception:                                     # noqa: BLE001 - a measurement aid must never fail the bench
+                return
+            stop.wait(0.3)
+
+    try:
+        cap = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", smi("--showmaxpower"))
+    except Exception:                                             # noqa: BLE001
+        return None
+    th = threading.Thread(target=sample, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
+    stop.set()
+    th.join(timeout=15)
+    rows = rows[1:] if len(rows) > 2 else rows                    # the first sample may predate the loop
+    if not rows:
+        return None
+    return {"package_w": sum(r[0] for r in rows) / len(rows), "cap_w": float(cap.group(1)) if cap else None,
+            "sclk_mhz": sum(r[1] for r in rows) / len(rows), "samples": len(rows),
+            "source": "rocm-smi --showpower --showclocks every ~0.5 s while the same step loops for %.1f s after the timed region" % seconds}
+
+
 def init_groups(dist, device, rank, world):
     """Control plane (barrier, max-over-ranks clock) on gloo; data plane (the per-layer halo slices) on RCCL
     point-to-point over xGMI.  The RCCL group is probed with one neighbour exchange before it is trusted; if any
@@ -264,6 +311,7 @@ def main():
                     help="weak: --frames per GPU (the job grows with N); strong: one clip of --total-frames split over the ranks")
     ap.add_argument("--total-frames", type=int, default=80, help="--scaling strong: frames of the whole clip (C4: 80)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power-probe", action="store_true", help="skip the 2.5 s rocm-smi power / clock sample after the timed region")
     ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["fp32", "f16x3"],
                     help="fp32: exact fp32 MFMA; f16x3: split-fp16 3-pass MFMA, fp32 accumulate (fp32-class accuracy)")
     args = ap.parse_args()
@@ -336,7 +384,7 @@ def main():
             return per_frame
         return lambda: model.clip_forward(x, halo_fn)
 
-    def timed_run(precision, steps, warmup, prewarm_s=0.0, instrument=True):
+    def timed_run(precision, steps, warmup, prewarm_s=0.0, instrument=True, probe_s=0.0):
         """W untimed + K timed steps of the hot path at `precision`; returns (model, max-over-ranks seconds, per-kernel
         launch timings, last output)."""
         model = build_model(device, precision, wl["blind"])
@@ -376,6 +424,9 @@ def main():
             if timer:
                 timer.detach()
                 agg = timer.summary()
+            model.bench_power = power_probe(step, probe_s) if (probe_s > 0 and world == 1) else None
+            if timer:
+                pass
             elif instrument:
                 # stream schedules replay HIP graphs (no per-launch host call to bracket): the per-kernel table comes from one
                 # extra, untimed pass of the same step with the engine issuing the same plans layer by layer
@@ -444,7 +495,7 @@ def main():
                 "conv_ms_per_step": sum(v["ms"] for v in agg.values()) / steps}
 
     # ---- the timed job (headline) ...
-    model, elapsed, agg, y = timed_run(args.precision, steps, warmup, args.prewarm_s)
+    model, elapsed, agg, y = timed_run(args.precision, steps, warmup, args.prewarm_s, probe_s=0.0 if args.no_power_probe else 2.5)
     stream_stats = getattr(model, "bench_stream_stats", None)
     model.release_stream_buffers()
     # ---- ... and, outside it, the other arithmetic mode on the same clip for reference + a live parity figure
@@ -494,6 +545,13 @@ def main():
                            "unit": "frames/s", "steps": steps_o, "ms_per_step": elapsed_o / steps_o * 1e3,
                            "roofline": roofline_of(agg_o, other, steps_o)},
         }
+        pw = getattr(model, "bench_power", None)
+        if pw:
+            # what the dominant kernel's MFMA work is against the matrix-pipe peak AT THE CLOCK THE CHIP ACTUALLY RUNS (2.4 GHz nominal)
+            scale = pw["sclk_mhz"] / 2400.0
+            pw["at_power_cap"] = bool(pw["cap_w"]) and pw["package_w"] >= 0.98 * pw["cap_w"]
+            pw["mfma_pipe_frac_at_sampled_clock"] = out["roofline"]["mfma_pipe_frac"] / scale if scale > 0 else None
+            out["power"] = pw
         if stream_stats:
             out["stream_engine"] = stream_stats
         if world > 1:
