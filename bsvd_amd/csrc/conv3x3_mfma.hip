@@ -57,7 +57,7 @@
 #define BSVD_TUNE_NARROW_OCC 3     // waves/SIMD the 128-px x 32-ch wave tile is compiled for (3: 168 VGPRs + a 12-byte spill; 2: no spill)
 #endif
 #ifndef BSVD_ABL
-#define BSVD_ABL 0             // TIMING-ONLY ablations of the prefetching K loop (results are wrong): 1 no chunk barrier, 2 no patch slices, 4 no weight loads, 8 half the weight loads (lo := hi), 16 all weight loads from two L1-resident slabs, 32 split epilogue without its stores, 64 split epilogue without the conversion, 128 split epilogue storing lane-contiguous 2-KB runs
+#define BSVD_ABL 0             // TIMING-ONLY ablations of the prefetching K loop (results are wrong): 1 no chunk barrier, 2 no patch slices, 4 no weight loads, 8 half the weight loads (lo := hi), 16 all weight loads from two L1-resident slabs, 32 split epilogue without its stores, 64 split epilogue without the conversion, 128 split epilogue storing lane-contiguous 2-KB runs, 256 pixel fragments read from LDS once per chunk instead of once per tap
 #endif
 #ifndef BSVD_TUNE_PASS_ORDER
 #define BSVD_TUNE_PASS_ORDER 0 // MFMA order inside a pass of the prefetching loops: 0 pixel-tile major, 1 channel-tile major
@@ -875,14 +875,14 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     __builtin_amdgcn_sched_barrier(0);                                                                   \
                     pass(LC, BCUR, 0);                                                      /* hi(w) x lo(x) */           \
                     __builtin_amdgcn_sched_barrier(0);                                                                   \
-                    if constexpr ((T) < 8) {                                                                             \
+                    if constexpr ((T) < 8 && !(BSVD_ABL & 256)) {                                                        \
                         load_lo(pcur, ((T) + 1) / 3, ((T) + 1) % 3, LN);                                                 \
                         if constexpr (!LITE) load_hi(pcur, ((T) + 1) / 3, ((T) + 1) % 3, HN);                            \
                     }                                                                                                    \
                     __builtin_amdgcn_sched_barrier(0);                                      /* reads stay HERE: 16 MFMAs of cover */ \
                     pass(HC, BCUR, 1);                                                      /* lo(w) x hi(x) */           \
                     pass(HC, BCUR, 0);                                                      /* hi(w) x hi(x) */           \
-                    if constexpr (LITE && (T) < 8) {                                                                     \
+                    if constexpr (LITE && (T) < 8 && !(BSVD_ABL & 256)) {                                                \
                         __builtin_amdgcn_sched_barrier(0);                                                               \
                         load_hi(pcur, ((T) + 1) / 3, ((T) + 1) % 3, HN);                                                 \
                         __builtin_amdgcn_sched_barrier(0);                                                               \
