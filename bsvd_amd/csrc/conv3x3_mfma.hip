@@ -69,7 +69,7 @@
 #define BSVD_TUNE_SKIP_DEAD 1  // 128-accumulator (LITE) tiles: waves entirely below the image issue no fragment reads / MFMAs
 #endif
 #ifndef BSVD_TUNE_APFL
-#define BSVD_TUNE_APFL 1       // prefetch of the next tap's fragments into the SAME registers (see LITE): bit 0 the 128-accumulator tiles, bit 1 the narrow 64-channel tile, bit 2 the exit tile, bit 3 the stride-2 tiles
+#define BSVD_TUNE_APFL 1       // prefetch of the next tap's fragments into the SAME registers (see LITE): bit 0 the 128-accumulator tiles (r03: 20.11 -> 19.56 ms per C1 clip), bit 1 the narrow 64-channel tile (5.05 -> 5.10), bit 2 the exit tile (=), bit 3 the stride-2 tiles (2.38 -> 2.42: third wave per SIMD lost)
 #endif
 #ifndef BSVD_TUNE_APF
 #define BSVD_TUNE_APF 1        // split DBUF tiles that request the NEXT tap's pixel fragments in the middle of the current tap: 0 none, 1 the exit tile (NT == 1), 2 all, 3 fat tiles
