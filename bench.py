@@ -231,8 +231,12 @@ def power_probe(step, seconds):
     import torch
     rows, stop = [], threading.Event()
 
+    # (a profiler wrapped around bench.py must not follow into the rocm-smi child)
+    env = {k: v for k, v in os.environ.items()
+           if not (k.startswith(("ROCP", "ROCPROF", "ROCTX")) or k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE"))}
+
     def smi(*flags):
-        return subprocess.run(["rocm-smi", *flags], capture_output=True, text=True, timeout=10).stdout
+        return subprocess.run(["rocm-smi", *flags], capture_output=True, text=True, timeout=10, env=env).stdout
 
     def sample():
         while not stop.is_set():
