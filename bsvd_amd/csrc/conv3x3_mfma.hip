@@ -1422,7 +1422,14 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
 #define BSVD_TUNE_THIN_ALT 0       // 1: small grids of the wide layers (single-frame launches) on <4,1,2,2,1> (256 px x 64 ch workgroups, two channel tiles)
 #endif
         if (p.Cout > 64) {
-            if (fat_wide >= fat_min) return launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
+#ifndef BSVD_TUNE_FAT_SHAPE
+#define BSVD_TUNE_FAT_SHAPE 0      // wave tile of the 256-px x 128-ch workgroup: 0 = 128 px x 64 ch (<4,2,2,2,1>), 1 = 256 px x 32 ch (<8,1,1,4,1>: half the
+                                   // weight bytes per MFMA, twice the pixel-fragment reads)
+#endif
+            if (fat_wide >= fat_min) {
+                if (BSVD_TUNE_FAT_SHAPE == 1) return launch_cfg<ConvCfg<8, 1, 1, 4, 1, 3>, true, 1>(p, stream, name, name_len);
+                return launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
+            }
             if (BSVD_TUNE_THIN_ALT) return launch_cfg<ConvCfg<4, 1, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
             return launch_cfg<ConvCfg<2, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
         }
