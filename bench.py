@@ -261,7 +261,8 @@ def power_probe(step, seconds):
         while time.perf_counter() - t0 < seconds:
             for _ in range(4):
                 step()
-            torch.cuda.synchronize()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
     stop.set()
     th.join(timeout=15)
     rows = rows[1:] if len(rows) > 2 else rows                    # the first sample may predate the loop

@@ -42,3 +42,27 @@ def test_stream_modes_refuse_more_than_one_rank():
     assert r.returncode != 0 and "single-GPU" in (r.stderr + r.stdout)
     r = _run("--gpus", "3", "--scaling", "strong", "--total-frames", "80", env={"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "not divisible" in (r.stderr + r.stdout)
+
+
+def test_power_probe_parses_rocm_smi_and_survives_its_absence(tmp_path, monkeypatch):
+    """bench.power_probe: package power / cap / shader clock from rocm-smi's text (a stand-in on PATH prints the real tool's
+    lines); without rocm-smi the probe returns None instead of failing the bench."""
+    sys.path.insert(0, ROOT)
+    import bench
+    fake = tmp_path / "rocm-smi"
+    fake.write_text("#!/bin/sh\n"
+                    "case \"$*\" in\n"
+                    "  *showmaxpower*) echo 'GPU[0]\t\t: Max Graphics Package Power (W): 1400.0';;\n"
+                    "  *) echo '============ ROCm System Management Interface ============'\n"
+                    "     echo 'GPU[0]\t\t: Current Socket Graphics Package Power (W): 1398.0'\n"
+                    "     echo 'GPU[0]\t\t: mclk clock level: 0: (2000Mhz)'\n"
+                    "     echo 'GPU[0]\t\t: sclk clock level: 1: (1620Mhz)';;\n"
+                    "esac\n")
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    calls = []
+    pw = bench.power_probe(lambda: calls.append(1), 1.2)
+    assert pw and pw["cap_w"] == 1400.0 and pw["package_w"] == 1398.0 and pw["sclk_mhz"] == 1620.0 and pw["samples"] >= 1
+    assert calls
+    monkeypatch.setenv("PATH", str(tmp_path / "nowhere"))
+    assert bench.power_probe(lambda: None, 0.1) is None
