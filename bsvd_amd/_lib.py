@@ -9,13 +9,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BSVD_HIP_LIB") or os.path.join(_HERE, "libbsvd_hip.so")   # env override: A/B tuning builds
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 BSVD_F32, BSVD_F16, BSVD_F16X3 = 0, 1, 2
 ACT = {"none": 0, "relu": 1, "relu6": 2}
 EPI_PLAIN, EPI_PS_ADD, EPI_RESID = 0, 1, 2
 
 EXPORTS = ("bsvd_abi_version", "bsvd_conv_args_size", "bsvd_last_error", "bsvd_conv3x3", "bsvd_conv3x3_variant", "bsvd_packed_weight_elems", "bsvd_pack_weights",
-           "bsvd_packed_head_weight_bytes", "bsvd_pack_head_weights",
+           "bsvd_packed_head_weight_bytes", "bsvd_pack_head_weights", "bsvd_packed_wino_weight_elems", "bsvd_pack_weights_wino",
            "bsvd_nchw_to_nhwc", "bsvd_nhwc_to_nchw", "bsvd_halo_pack", "bsvd_halo_unpack", "bsvd_workspace_bytes",
            "bsvd_u8_to_planar", "bsvd_planar_to_u8", "bsvd_conv3x3_batch", "bsvd_graph_begin", "bsvd_graph_fork",
            "bsvd_graph_join", "bsvd_graph_end", "bsvd_graph_abort", "bsvd_graph_launch", "bsvd_graph_destroy")
@@ -50,6 +50,8 @@ class BsvdConvArgs(ctypes.Structure):
         ("tile_order", ctypes.c_int32),
         ("head_w_packed", ctypes.c_void_p),
         ("head_bias", ctypes.c_void_p),
+        ("w_wino_packed", ctypes.c_void_p),
+        ("wino_m", ctypes.c_int32),
     ]
 
 
@@ -85,6 +87,10 @@ def load():
     lib.bsvd_packed_weight_elems.argtypes = [i32, i32]
     lib.bsvd_pack_weights.restype = ctypes.c_int
     lib.bsvd_pack_weights.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.bsvd_packed_wino_weight_elems.restype = i64
+    lib.bsvd_packed_wino_weight_elems.argtypes = [i32, i32, i32]
+    lib.bsvd_pack_weights_wino.restype = ctypes.c_int
+    lib.bsvd_pack_weights_wino.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.bsvd_packed_head_weight_bytes.restype = i64
     lib.bsvd_packed_head_weight_bytes.argtypes = [i32]
     lib.bsvd_pack_head_weights.restype = ctypes.c_int

@@ -9,6 +9,7 @@ the C ABI (include/bsvd_hip.h).  The module tree only HOLDS the parameters (so `
 """
 from collections import OrderedDict
 
+import os
 import warnings
 
 import numpy as np
@@ -35,6 +36,9 @@ for _hook in ("register_module_parameter_registration_hook", "register_module_bu
               "register_module_module_registration_hook"):
     getattr(torch.nn.modules.module, _hook)(_bump_epoch)
 
+# Arithmetic form of the wide stride-1 layers in the split mode (engine.wino_eligible): 'direct' (3-pass implicit GEMM),
+# 'wino2' / 'wino4' (1-D Winograd F(2,3) / F(4,3) along x, conv3x3_wino.hip).  wide_conv='auto' takes BSVD_WIDE_CONV or this.
+WIDE_CONV_DEFAULT = "direct"
 F16X3_WEIGHT_LIMIT = 6.0e4      # |folded weight| beyond this cannot be carried as an fp16 pair (fp16 max 65504)
 
 
@@ -94,9 +98,15 @@ def _denblock_params(chns, in_ch, out_ch, interm_ch, blind, norm="none"):
 class _HipNet(nn.Module):
     """Shared engine plumbing of the registered arch classes: NetSpec, precision, weight (re)packing, executor."""
 
-    def _init_engine(self, net, precision, clamp, norm='none'):
+    def _init_engine(self, net, precision, clamp, norm='none', wide_conv='auto'):
         if precision not in ("auto", "fp32", "f16x3"):
             raise ValueError("precision must be 'auto', 'fp32' or 'f16x3'")
+        if wide_conv == "auto":
+            wide_conv = os.environ.get("BSVD_WIDE_CONV", WIDE_CONV_DEFAULT)
+        from .engine import WIDE_CONV
+        if wide_conv not in WIDE_CONV:
+            raise ValueError("wide_conv must be 'auto' or one of %s" % (WIDE_CONV,))
+        self.wide_conv = wide_conv
         if norm not in ("none", "bn"):
             raise NotImplementedError("norm=%r: 'none' (the shipped configs, options/test/bsvd_c64.yml:90) and 'bn' (the "
                                       "constructor default; eval-mode statistics folded into the packed conv weights) are "
@@ -189,7 +199,7 @@ class _HipNet(nn.Module):
                                "running statistics; call .eval() first (DenoisingModel.test and profile.py do: "
                                "denoising_model.py:180, profile.py:80).  Training is out of scope of this engine.")
         require_hip()
-        sig = (self._signature(), str(device), self.precision)
+        sig = (self._signature(), str(device), self.precision, self.wide_conv)
         if self._packed is None or self._packed_sig != sig:
             # the ring/graph engines of the stream schedule bake the packed-weight addresses into their launch plans: drop them
             # BEFORE the old pack is freed (a new executor may even reuse the old one's id())
@@ -207,11 +217,11 @@ class _HipNet(nn.Module):
                         warnings.warn("bsvd_amd: max |weight| after the BatchNorm fold is %.3g, outside fp16's range: "
                                       "precision='auto' falls back to exact fp32 for this network" % wmax)
                         self.precision = "fp32"
-                        sig = (sig[0], sig[1], self.precision)
+                        sig = (sig[0], sig[1], self.precision, self.wide_conv)
                     else:
                         raise ValueError("precision='f16x3': max |weight| after the BatchNorm fold is %.3g, outside fp16's "
                                          "range (use precision='fp32' or 'auto')" % wmax)
-            self._packed = PackedNet(self.net, state, device, self.precision)
+            self._packed = PackedNet(self.net, state, device, self.precision, self.wide_conv)
             self._packed_sig = sig
             self._exec = HipExecutor(self._packed)
             self._exec_gen = getattr(self, "_exec_gen", 0) + 1
@@ -282,14 +292,14 @@ class BSVD(_HipNet):
     def __init__(self, chns=[32, 64, 128], mid_ch=3, shift_input=False, in_ch=4, out_ch=3, norm='bn', act='relu',
                  interm_ch=30, blind=False, pretrain_ckpt='./experiments/pretrained_ckpt/bsvd-64.pth',
                  engine_mode='auto', clamp=None, precision='auto', stream_overlap=True, stream_rings=True,
-                 stream_graphs=True, stream_chunk='auto'):
+                 stream_graphs=True, stream_chunk='auto', wide_conv='auto'):
         super().__init__()
         if shift_input:
             raise NotImplementedError("shift_input=True (CvBlock input stage) is not used by any BSVD config; "
                                       "the reference itself is inconsistent there (SURVEY.md §8a-16)")
         if engine_mode not in ("auto", "clip", "stream"):
             raise ValueError("engine_mode must be 'auto', 'clip' or 'stream'")
-        self._init_engine(make_netspec(chns, mid_ch, in_ch, out_ch, act, interm_ch, blind), precision, clamp, norm)
+        self._init_engine(make_netspec(chns, mid_ch, in_ch, out_ch, act, interm_ch, blind), precision, clamp, norm, wide_conv)
         self.engine_mode = engine_mode
         self.last_mode = None          # schedule the last forward() actually ran ('clip' | 'stream')
         self.stream_overlap = bool(stream_overlap)   # streaming_forward: temp1(step k) and temp2(step k-1) as parallel graph branches
@@ -647,7 +657,7 @@ class TSN(_HipNet):
     (``base_model.nets_list.{0,1}...``), so ``bsvd-64.pth``-style files load with ``load_state_dict`` directly."""
 
     def __init__(self, num_segments=11, base_model='WNet_multistage', shift_type='TSM', shift_div=8, inplace=False,
-                 net2d_opt={}, enable_past_buffer=True, clamp=None, precision='auto', **kwargs):
+                 net2d_opt={}, enable_past_buffer=True, clamp=None, precision='auto', wide_conv='auto', **kwargs):
         super().__init__()
         if base_model != 'WNet_multistage':
             raise NotImplementedError("base_model %r" % (base_model,))
@@ -661,7 +671,7 @@ class TSN(_HipNet):
         self.num_segments = num_segments
         self.enable_past_buffer = enable_past_buffer
         self._init_engine(make_netspec(o['chns'], o['mid_ch'], o['in_ch'], o['out_ch'], o['act'], o['interm_ch'],
-                                       o['blind']), precision, clamp, o['norm'])
+                                       o['blind']), precision, clamp, o['norm'], wide_conv)
         n = self.net
         stages = []
         for args_ in ((o['in_ch'], o['mid_ch'], o['blind']), (o['mid_ch'], o['out_ch'], False)):

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "bsvd_internal.h"
+#include "wino_forms.h"
 
 namespace bsvd {
 
@@ -87,6 +88,56 @@ __global__ void pack_weights_split_kernel(const float *__restrict__ w, const flo
         const float v = ok ? w[((int64_t)n * Cin + c) * 9 + tap] : 0.f;
         const _Float16 hi = (_Float16)v;
         wp[i] = part ? lo_keep((_Float16)(v - (float)hi)) : hi;
+        if (bp && i < Cout_pad) {
+            int nb = (int)i;
+            bool okb;
+            if (ps) {
+                const int sub = nb / Cq_pad, ch = nb - sub * Cq_pad;
+                okb = ch < Cq;
+                nb = 4 * ch + sub;
+            } else {
+                okb = nb < Cout;
+            }
+            bp[i] = (okb && bias) ? bias[nb] : 0.f;
+        }
+    }
+}
+
+// Winograd weights (conv3x3_wino.hip): [Cin_pad/16][A][3 ky][part: hi, lo][h = 2][Cout_pad][8 fp16], U = G g along kx in double
+struct WinoG { double g[8][3]; int a; };
+__global__ void pack_weights_wino_kernel(const float *__restrict__ w, const float *__restrict__ bias, int Cin, int Cout,
+                                         int Cin_pad, int Cout_pad, int ps, WinoG G, _Float16 *__restrict__ wp,
+                                         float *__restrict__ bp)
+{
+    const int A = G.a;
+    const int64_t total = (int64_t)Cin_pad * 3 * A * Cout_pad * 2;
+    const int Cq_pad = Cout_pad >> 2, Cq = Cout >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int j = t & 7; t >>= 3;
+        const int np = (int)(t % Cout_pad); t /= Cout_pad;
+        const int h = t & 1; t >>= 1;
+        const int part = t & 1; t >>= 1;
+        const int ky = (int)(t % 3); t /= 3;
+        const int xi = (int)(t % A);
+        const int cb = (int)(t / A);
+        const int c = cb * 16 + h * 8 + j;
+        int n = np;
+        bool ok = c < Cin;
+        if (ps) {
+            const int sub = np / Cq_pad, ch = np - sub * Cq_pad;
+            ok = ok && ch < Cq;
+            n = 4 * ch + sub;
+        } else {
+            ok = ok && np < Cout;
+        }
+        double u = 0.0;
+        if (ok) {
+            const float *g = w + ((int64_t)n * Cin + c) * 9 + ky * 3;
+            u = G.g[xi][0] * (double)g[0] + G.g[xi][1] * (double)g[1] + G.g[xi][2] * (double)g[2];
+        }
+        const _Float16 hi = (_Float16)u;
+        wp[i] = part ? lo_keep((_Float16)(u - (double)hi)) : hi;
         if (bp && i < Cout_pad) {
             int nb = (int)i;
             bool okb;
@@ -247,7 +298,7 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
 {
     if (!a) { set_error("bsvd_conv3x3: args is NULL"); return -1; }
     if (a->dtype != BSVD_F32 && a->dtype != BSVD_F16X3) { set_error("bsvd_conv3x3: dtype %d not supported (BSVD_F32, BSVD_F16X3)", a->dtype); return -2; }
-    if (!a->x || !a->y || !a->w_packed) { set_error("bsvd_conv3x3: x, y and w_packed must be non-NULL"); return -3; }
+    if (!a->x || !a->y || !(a->w_packed || a->w_wino_packed)) { set_error("bsvd_conv3x3: x, y and w_packed (or w_wino_packed) must be non-NULL"); return -3; }
     if (a->frames <= 0 || a->H <= 0 || a->W <= 0) { set_error("bsvd_conv3x3: bad clip size %d x %d x %d", a->frames, a->H, a->W); return -4; }
     if (a->Cin <= 0 || (a->Cin & 15) || a->Cout <= 0 || (a->Cout & 15)) {
         set_error("bsvd_conv3x3: Cin=%d / Cout=%d must be positive multiples of 16 (pad channels)", a->Cin, a->Cout);
@@ -269,7 +320,8 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
     p.x = (const float *)a->x;
     p.halo_prev = a->fold > 0 ? (const float *)a->halo_prev : nullptr;
     p.halo_next = a->fold > 0 ? (const float *)a->halo_next : nullptr;
-    p.w = (const float *)a->w_packed;
+    p.w = (const float *)(a->w_wino_packed ? a->w_wino_packed : a->w_packed);
+    p.wino_m = a->w_wino_packed ? a->wino_m : 0;
     p.bias = (const float *)a->bias_packed;
     p.extra = (const float *)a->extra;
     p.y = (float *)a->y;
@@ -297,7 +349,12 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
 #ifdef BSVD_ABLATE
     if (const char *e = getenv("BSVD_ABLATE")) p.ablate = atoi(e);
 #endif
-    if ((((uintptr_t)a->w_packed) & 15) != 0) { set_error("bsvd_conv3x3: w_packed must be 16-byte aligned"); return -13; }
+    if ((((uintptr_t)p.w) & 15) != 0) { set_error("bsvd_conv3x3: w_packed / w_wino_packed must be 16-byte aligned"); return -13; }
+    if (a->w_wino_packed) {      // Winograd form of a wide layer: explicit request, no silent fall-back to the direct kernel
+        if (a->x_planar_ch > 0 || a->head_w_packed) { set_error("bsvd_conv3x3: w_wino_packed: not with a planar / fused entry"); return -19; }
+        if (const char *why = wino_unsupported(p, a->stride)) { set_error("bsvd_conv3x3: w_wino_packed (F(%d,3)): %s", a->wino_m, why); return -19; }
+        return p.wino_m >= 10 ? launch_wino(p, (hipStream_t)stream, name, name_len) : launch_winox(p, (hipStream_t)stream, name, name_len);
+    }
     if (a->x_planar_ch > 0 || a->y_planar_ch > 0) {
         if (a->x_planar_ch > 0 && a->y_planar_ch > 0) { set_error("bsvd_conv3x3: x_planar_ch and y_planar_ch are exclusive"); return -16; }
         if (a->stride != 1 || a->fold != 0) { set_error("bsvd_conv3x3: planar edge layers need stride 1 and fold 0"); return -16; }
@@ -339,6 +396,28 @@ int bsvd_conv3x3_variant(const BsvdConvArgs *a, char *name, int32_t name_len)
     if (!name || name_len < 8) { set_error("bsvd_conv3x3_variant: name buffer too small"); return -1; }
     name[0] = 0;
     return conv3x3_impl(a, nullptr, name, name_len);
+}
+
+int64_t bsvd_packed_wino_weight_elems(int32_t Cin_pad, int32_t Cout_pad, int32_t m) { return (int64_t)Cin_pad * 3 * (m + 2) * Cout_pad; }
+
+int bsvd_pack_weights_wino(const float *w, const float *bias, int32_t Cin, int32_t Cout, int32_t Cin_pad, int32_t Cout_pad,
+                           int32_t pixel_shuffle, int32_t m, void *wp, void *bp, void *stream)
+{
+    if (m != 2 && m != 4 && m != 6) { set_error("bsvd_pack_weights_wino: m = %d (2, 4 or 6)", m); return -2; }
+    if (!w || !wp) { set_error("bsvd_pack_weights_wino: NULL weight pointer"); return -3; }
+    if (Cin <= 0 || Cout <= 0 || Cin_pad < Cin || Cout_pad < Cout || (Cin_pad & 15) || (Cout_pad & 31)) {
+        set_error("bsvd_pack_weights_wino: bad sizes Cin %d->%d Cout %d->%d (Cin_pad %% 16, Cout_pad %% 32)", Cin, Cin_pad, Cout, Cout_pad); return -5;
+    }
+    if (pixel_shuffle && ((Cout & 3) || (Cout_pad & 63))) { set_error("bsvd_pack_weights_wino: pixel_shuffle needs Cout %% 4 == 0 and Cout_pad %% 64 == 0"); return -10; }
+    WinoG G;
+    G.a = m + 2;
+    for (int x = 0; x < 8; ++x)
+        for (int k = 0; k < 3; ++k)
+            G.g[x][k] = x >= m + 2 ? 0.0 : (m == 6 ? WinoForm<6>::G[x][k] : m == 4 ? WinoForm<4>::G[x < 6 ? x : 0][k] : WinoForm<2>::G[x < 4 ? x : 0][k]);
+    const int64_t total = (int64_t)Cin_pad * 3 * (m + 2) * Cout_pad * 2;
+    hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, w, bias, Cin, Cout,
+                       Cin_pad, Cout_pad, pixel_shuffle ? 1 : 0, G, (_Float16 *)wp, (float *)bp);
+    return (int)hipGetLastError();
 }
 
 int bsvd_pack_weights(const float *w, const float *bias, int32_t Cin, int32_t Cout, int32_t Cin_pad, int32_t Cout_pad,

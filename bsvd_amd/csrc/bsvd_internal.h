@@ -34,6 +34,8 @@ struct ConvParams {
     const void *head_w;
     const float *head_bias;
     int32_t head_cin;
+    // Winograd form of the wide split-fp16 layers (BsvdConvArgs.w_wino_packed): w then points at the transformed pack
+    int32_t wino_m;          // 0 = direct convolution; 2 | 4 | 6 = F(wino_m, 3) along x (conv3x3_winox.hip); 12 | 14 = the all-positions-per-wave kernel (conv3x3_wino.hip)
 };
 
 void set_error(const char *fmt, ...);
@@ -75,6 +77,12 @@ inline hipError_t ensure_dynamic_lds(const void *fn, int bytes, std::atomic<int>
 // conv3x3_mfma.hip
 // name != nullptr: dry run, only writes the kernel instantiation that would be launched
 int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *name = nullptr, int name_len = 0);
+
+// conv3x3_wino.hip
+const char *wino_unsupported(const ConvParams &p, int stride);     // nullptr = the Winograd kernel can run this layer
+int launch_wino(const ConvParams &p, hipStream_t stream, char *name = nullptr, int name_len = 0);
+// conv3x3_winox.hip (one transformed position per wave; wino_m 2 | 4 | 6)
+int launch_winox(const ConvParams &p, hipStream_t stream, char *name = nullptr, int name_len = 0);
 
 // conv3x3_edge_f32.hip
 int launch_head_f32(const ConvParams &p, int cin_real, hipStream_t stream);

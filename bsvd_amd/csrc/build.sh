@@ -11,14 +11,14 @@ OUT="${BSVD_OUT:-$ROOT/bsvd_amd/libbsvd_hip.so}"
 OBJ="$HERE/obj${BSVD_OBJ_SUFFIX:-}"
 mkdir -p "$OBJ"
 pids=()
-for src in conv3x3_mfma conv3x3_edge_f32 bsvd_abi; do
+for src in conv3x3_mfma conv3x3_wino conv3x3_winox conv3x3_edge_f32 bsvd_abi; do
   if [ ! -f "$OBJ/$src.o" ] || [ "$HERE/$src.hip" -nt "$OBJ/$src.o" ] || \
-     [ "$HERE/bsvd_internal.h" -nt "$OBJ/$src.o" ] || [ "$ROOT/include/bsvd_hip.h" -nt "$OBJ/$src.o" ] || \
+     [ "$HERE/bsvd_internal.h" -nt "$OBJ/$src.o" ] || [ "$HERE/wino_forms.h" -nt "$OBJ/$src.o" ] || [ "$ROOT/include/bsvd_hip.h" -nt "$OBJ/$src.o" ] || \
      [ "$(cat "$OBJ/$src.flags" 2>/dev/null)" != "$FLAGS" ]; then
     ( $HIPCC $FLAGS -c "$HERE/$src.hip" -o "$OBJ/$src.o" && echo "$FLAGS" > "$OBJ/$src.flags" ) &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$OBJ/conv3x3_mfma.o" "$OBJ/conv3x3_edge_f32.o" "$OBJ/bsvd_abi.o" -o "$OUT"
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$OBJ/conv3x3_mfma.o" "$OBJ/conv3x3_wino.o" "$OBJ/conv3x3_winox.o" "$OBJ/conv3x3_edge_f32.o" "$OBJ/bsvd_abi.o" -o "$OUT"
 echo "built $OUT"

@@ -35,14 +35,33 @@ def head_fusable(inc0, inc3, precision):
             and not inc3.tsm and inc3.epilogue == EPI_PLAIN and inc0.act == inc3.act)
 
 
+WIDE_CONV = ("direct", "wino2", "wino4", "wino6", "wino2b", "wino4b")
+
+
+def wino_eligible(sp, precision):
+    """Layers the 1-D Winograd kernel (conv3x3_wino.hip) can take: the wide stride-1 layers of the split-fp16 mode --
+    the temporal-fusion convs (bsvd_arch.py:21-50) and the UpBlock convs (:257-267) at >= 128 input channels.  The choice
+    depends on the LAYER only (never on the clip length or frame size), so that every schedule -- clip, stream, sharded,
+    MIMO -- runs the same arithmetic per layer and stays bit-identical to the others."""
+    return (precision == "f16x3" and sp.stride == 1 and sp.cin_pad >= 128 and sp.cout_pad % 32 == 0
+            and sp.epilogue in (EPI_PLAIN, EPI_PS_ADD) and (not sp.tsm or sp.fold % 16 == 0))
+
+
 class PackedNet:
     """Device-resident pre-packed weights of every layer (one-time transform of the state_dict,
     cf. BSVD.load, bsvd_arch.py:462-474): {spec.key: (w_packed, bias_packed)}."""
 
-    def __init__(self, net, state, device, precision="fp32"):
+    def __init__(self, net, state, device, precision="fp32", wide_conv="direct"):
         lib = require_hip()
+        if wide_conv not in WIDE_CONV:
+            raise ValueError("wide_conv must be one of %s" % (WIDE_CONV,))
         self.device = device
         self.precision = precision
+        self.wide_conv = wide_conv
+        # F(m,3) form; the ABI's wino_m + 10 selects the all-positions-per-wave kernel (conv3x3_wino.hip, measurement variant)
+        self.wino_m = {"direct": 0, "wino2": 2, "wino4": 4, "wino6": 6, "wino2b": 2, "wino4b": 4}[wide_conv]
+        self.wino_abi = self.wino_m + (10 if wide_conv.endswith("b") else 0)
+        self.wino = {}               # {spec.key: transformed pack} of the layers that run on the Winograd kernel
         self.tensors = {}
         self.order = {sp.key: i for i, sp in enumerate(net.layers)}      # position in the layer-major walk (tile_order parity)
         edge = set()
@@ -58,9 +77,19 @@ class PackedNet:
                     b = b.detach().to(device=device, dtype=torch.float32).contiguous()
                 if tuple(w.shape) != (sp.cout, sp.cin, 3, 3):
                     raise ValueError("%s.weight has shape %s, expected %s" % (sp.key, tuple(w.shape), (sp.cout, sp.cin, 3, 3)))
+                bp = torch.empty(sp.cout_pad, dtype=torch.float32, device=device)
+                if self.wino_m and wino_eligible(sp, precision):
+                    n = lib.bsvd_packed_wino_weight_elems(sp.cin_pad, sp.cout_pad, self.wino_m)
+                    wq = torch.empty(n, dtype=torch.float32, device=device)
+                    rc = lib.bsvd_pack_weights_wino(w.data_ptr(), b.data_ptr() if b is not None else None, sp.cin, sp.cout,
+                                                    sp.cin_pad, sp.cout_pad, 1 if sp.epilogue == EPI_PS_ADD else 0, self.wino_m,
+                                                    wq.data_ptr(), bp.data_ptr(), _stream_ptr())
+                    _lib.check(rc, "bsvd_pack_weights_wino(%s)" % sp.key)
+                    self.wino[sp.key] = wq
+                    self.tensors[sp.key] = (None, bp)
+                    continue
                 n = lib.bsvd_packed_weight_elems(sp.cin_pad, sp.cout_pad)
                 wp = torch.empty(n, dtype=torch.float32, device=device)
-                bp = torch.empty(sp.cout_pad, dtype=torch.float32, device=device)
                 dt = _lib.BSVD_F16X3 if (precision == "f16x3" and sp.key not in edge) else _lib.BSVD_F32
                 rc = lib.bsvd_pack_weights(w.data_ptr(), b.data_ptr() if b is not None else None, sp.cin, sp.cout,
                                            sp.cin_pad, sp.cout_pad, 1 if sp.epilogue == EPI_PS_ADD else 0, dt,
@@ -257,7 +286,11 @@ class HipExecutor:
                 a.halo_prev, a.halo_prev_pstride, a.halo_prev_coff = halo_prev.t.data_ptr(), halo_prev.pstride, halo_prev.coff
             if halo_next is not None:
                 a.halo_next, a.halo_next_pstride, a.halo_next_coff = halo_next.t.data_ptr(), halo_next.pstride, halo_next.coff
-        a.w_packed, a.bias_packed = wp.data_ptr(), bp.data_ptr()
+        a.bias_packed = bp.data_ptr()
+        if wp is not None:
+            a.w_packed = wp.data_ptr()
+        else:
+            a.w_wino_packed, a.wino_m = self.packed.wino[sp.key].data_ptr(), self.packed.wino_abi
         if extra is not None:
             a.extra = extra.data_ptr()
             a.extra_frame_stride = extra[0].numel()

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BSVD_ABI_VERSION 8
+#define BSVD_ABI_VERSION 9
 
 /* dtype.  BSVD_F32: exact fp32 (v_mfma_f32_32x32x2_f32).  BSVD_F16X3 ("split16"): every fp32 value v is carried as
  * an fp16 pair hi = fp16(v), lo = fp16(v - hi); a 16-channel chunk of a pixel is stored as [hi x16 | lo x16] in the
@@ -114,6 +114,17 @@ typedef struct BsvdConvArgs {
      * BSVD_EPI_PLAIN; both convs share `act`.  head_w_packed: bsvd_pack_head_weights(); head_bias: [Cin] fp32. */
     const void *head_w_packed;
     const void *head_bias;
+    /* Winograd form of a wide layer (ABI v9, BSVD_F16X3 only).  w_wino_packed != NULL selects the 1-D Winograd F(wino_m, 3)
+     * kernel (wino_m = 2, 4 or 6; conv3x3_winox.hip, one transformed position per wave; wino_m + 10 = 12 | 14 runs the
+     * all-positions-per-wave variant conv3x3_wino.hip on the same F(2,3) / F(4,3) pack -- kept for measurements) with the
+     * TRANSFORMED weights of bsvd_pack_weights_wino(); w_packed is then
+     * ignored (may be NULL).  Same contract and tensors as the direct form -- gather, halos, bias, activation, PLAIN / PS_ADD
+     * epilogues -- but 6 (F(2,3)), 4.5 (F(4,3)) or 4 (F(6,3)) instead of 9 tap-GEMMs per output pixel; results differ from the direct
+     * form in the last bits (fp32 transforms, both inside the same error class: 5e-5 max-abs on bsvd_c64), so a host must use
+     * ONE form per layer in every schedule it wants bit-identical (clip / stream / sharded).  Needs stride 1, fold % 16 == 0,
+     * Cout % 32 == 0, no planar / fused-entry / RESID options; anything else returns -19 with the reason. */
+    const void *w_wino_packed;
+    int32_t wino_m;
 } BsvdConvArgs;
 
 int bsvd_abi_version(void);
@@ -140,6 +151,18 @@ int64_t bsvd_packed_weight_elems(int32_t Cin_pad, int32_t Cout_pad);
 int bsvd_pack_weights(const float *w_oihw, const float *bias, int32_t Cin, int32_t Cout,
                       int32_t Cin_pad, int32_t Cout_pad, int32_t pixel_shuffle, int32_t dtype,
                       void *w_packed, void *bias_packed, void *stream);
+
+/*
+ * Weights of the Winograd form (BsvdConvArgs.w_wino_packed): U[xi][ky] = sum_kx G[xi][kx] * w[.][.][ky][kx] for the
+ * m + 2 transformed positions xi of F(m, 3), m = 2 | 4 | 6 (bsvd_amd/csrc/wino_forms.h), computed in double precision, split into fp16
+ * pairs and laid out [Cin_pad/16][m + 2][3][hi, lo][2][Cout_pad][8 fp16]; pixel_shuffle permutes the output channels like
+ * bsvd_pack_weights.  w_packed needs bsvd_packed_wino_weight_elems(Cin_pad, Cout_pad, m) 4-byte elements; bias_packed
+ * (nullable) [Cout_pad] fp32 as in bsvd_pack_weights.
+ */
+int64_t bsvd_packed_wino_weight_elems(int32_t Cin_pad, int32_t Cout_pad, int32_t m);
+int bsvd_pack_weights_wino(const float *w_oihw, const float *bias, int32_t Cin, int32_t Cout, int32_t Cin_pad,
+                           int32_t Cout_pad, int32_t pixel_shuffle, int32_t m, void *w_packed, void *bias_packed,
+                           void *stream);
 
 /*
  * Weights of the fused network entry (BsvdConvArgs.head_w_packed): the first conv's [Cmid][Cin][3][3] (Cin = 3 or 4) as the

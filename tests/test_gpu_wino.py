@@ -1,0 +1,96 @@
+"""Parity of the 1-D Winograd form of the wide split-fp16 layers (bsvd_amd/csrc/conv3x3_wino.hip, BsvdConvArgs.w_wino_packed)
+against the CPU oracle (double-accumulating conv) -- F(2,3) and F(4,3), every operand form the direct kernel's tests cover:
+zero / compact / full-frame halos (bsvd_arch.py:94,104,112-113), PixelShuffle + skip add (:263-267, :402), ragged sizes,
+sub-tiles below / right of the image, an odd number of sub-tiles per frame, the zero-chunk skip of a clip's end frames."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import maxabs
+from oracle_exec import OracleExecutor
+from seeded import seeded_state
+from test_gpu_f16x3 import _Net, from_split, to_split
+
+pytestmark = pytest.mark.gpu
+TIGHT = 2e-4
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _exec(net, st, wide_conv):
+    from bsvd_amd.engine import HipExecutor, PackedNet
+    return HipExecutor(PackedNet(net, {k: torch.as_tensor(v) for k, v in st.items()}, _dev(), "f16x3", wide_conv))
+
+
+CASES = [
+    # cin, cout, tsm, act, epi, T, H, W
+    (128, 128, True, "relu6", 0, 3, 10, 19),       # ragged in x and y, three temporal sources
+    (128, 128, True, "relu6", 0, 1, 16, 16),       # exactly one sub-tile (second one of the pair dead); single frame: both sources halos
+    (256, 256, True, "relu", 0, 2, 9, 17),
+    (128, 128, False, "none", 0, 2, 35, 48),       # three sub-tile rows of F(4,3), five of F(2,3); odd sub-tile count per frame
+    (256, 512, False, "none", 1, 2, 9, 13),        # UpBlock: PixelShuffle + skip add, four channel tiles
+    (128, 256, False, "none", 1, 1, 12, 20),
+    (128, 128, True, "relu6", 0, 4, 40, 64),       # several workgroups per frame
+]
+
+
+@pytest.mark.parametrize("wide_conv", ["wino2", "wino4", "wino6", "wino2b"])
+@pytest.mark.parametrize("cin,cout,tsm,act,epi,T,H,W", CASES)
+def test_wino_layer_vs_oracle(wide_conv, cin, cout, tsm, act, epi, T, H, W):
+    from bsvd_amd.netspec import ConvSpec
+    from bsvd_amd.schedule import Halo
+    rs = np.random.RandomState(cin + cout + H)
+    sp = ConvSpec("l", "l", cin, cout, 1, tsm, act, epi)
+    st = seeded_state([("e0.weight", (16, 4, 3, 3)), ("e0.bias", (16,)), ("l.weight", (cout, cin, 3, 3)),
+                       ("l.bias", (cout,)), ("e1.weight", (3, 16, 3, 3)), ("e1.bias", (3,))], 7)
+    gex, oex = _exec(_Net(sp), st, wide_conv), OracleExecutor(st, double=True)
+    assert "l" in gex.packed.wino
+    x = torch.from_numpy(rs.standard_normal((T, H, W, cin)).astype(np.float32))
+    extra = extra_dev = None
+    eps = 0
+    if epi == 1:
+        extra = torch.from_numpy(rs.standard_normal((T, 2 * H, 2 * W, cout // 4)).astype(np.float32))
+        extra = from_split(to_split(extra))
+        extra_dev, eps = to_split(extra).to(_dev()), cout // 4
+    xq = from_split(to_split(x))
+    halos = [(None, None)]
+    if tsm:
+        fold = sp.fold
+        hp = from_split(to_split(torch.from_numpy(rs.standard_normal((H, W, fold)).astype(np.float32))))
+        hn = from_split(to_split(torch.from_numpy(rs.standard_normal((H, W, fold)).astype(np.float32))))
+        halos.append((Halo(hp, fold, 0), Halo(hn, fold, 0)))
+        full = from_split(to_split(torch.from_numpy(rs.standard_normal((1, H, W, cin)).astype(np.float32))))
+        halos.append((Halo(full, cin, fold), Halo(full, cin, 0)))
+        halos.append((None, Halo(hn, fold, 0)))
+    gex.record_variants = True
+    for hp, hn in halos:
+        want = oex.conv(sp, xq, hp, hn, extra, eps, 1)
+        d = lambda h: None if h is None else Halo(to_split(h.t).to(_dev()), h.pstride, h.coff)
+        got = from_split(gex.conv(sp, to_split(x).to(_dev()), d(hp), d(hn), extra_dev, eps, 1).cpu())
+        assert "_kernel<F(%s,3)" % wide_conv[4] in gex.last_variant and gex.last_variant.startswith("wino_" if wide_conv.endswith("b") else "winox_"), gex.last_variant
+        err = maxabs(got.numpy(), want.numpy())
+        print("%s layer %s max-abs %.3e (|y| max %.1f)" % (wide_conv, (cin, cout, tsm, epi, T, H, W), err, float(want.abs().max())))
+        assert err < TIGHT
+
+
+@pytest.mark.parametrize("wide_conv", ["wino2", "wino6"])
+def test_wino_refuses_what_it_cannot_run(wide_conv):
+    """an explicit w_wino_packed never falls back silently: stride 2 / RESID / odd fold return -19 with the reason"""
+    import ctypes
+    from bsvd_amd import _lib
+    from bsvd_amd.netspec import ConvSpec
+    sp = ConvSpec("l", "l", 128, 128, 1, True, "relu6", 0)
+    st = seeded_state([("e0.weight", (16, 4, 3, 3)), ("e0.bias", (16,)), ("l.weight", (128, 128, 3, 3)),
+                       ("l.bias", (128,)), ("e1.weight", (3, 16, 3, 3)), ("e1.bias", (3,))], 7)
+    gex = _exec(_Net(sp), st, wide_conv)
+    x = to_split(torch.zeros(1, 8, 16, 128)).to(_dev())
+    a, _ = gex.build_args(sp, x)
+    lib = _lib.load()
+    a.stride = 2
+    assert lib.bsvd_conv3x3(ctypes.byref(a), None) == -19 and b"stride" in lib.bsvd_last_error()
+    a.stride, a.fold = 1, 8
+    assert lib.bsvd_conv3x3(ctypes.byref(a), None) == -19 and b"fold" in lib.bsvd_last_error()
+    a.fold, a.wino_m = 16, 3
+    assert lib.bsvd_conv3x3(ctypes.byref(a), None) == -19
