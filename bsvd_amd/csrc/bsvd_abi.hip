@@ -353,7 +353,7 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
     if (a->w_wino_packed) {      // Winograd form of a wide layer: explicit request, no silent fall-back to the direct kernel
         if (a->x_planar_ch > 0 || a->head_w_packed) { set_error("bsvd_conv3x3: w_wino_packed: not with a planar / fused entry"); return -19; }
         if (const char *why = wino_unsupported(p, a->stride)) { set_error("bsvd_conv3x3: w_wino_packed (F(%d,3)): %s", a->wino_m, why); return -19; }
-        return p.wino_m >= 10 ? launch_wino(p, (hipStream_t)stream, name, name_len) : launch_winox(p, (hipStream_t)stream, name, name_len);
+        return (p.wino_m >= 10 && p.wino_m < 20) ? launch_wino(p, (hipStream_t)stream, name, name_len) : launch_winox(p, (hipStream_t)stream, name, name_len);
     }
     if (a->x_planar_ch > 0 || a->y_planar_ch > 0) {
         if (a->x_planar_ch > 0 && a->y_planar_ch > 0) { set_error("bsvd_conv3x3: x_planar_ch and y_planar_ch are exclusive"); return -16; }

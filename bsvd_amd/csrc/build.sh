@@ -8,14 +8,17 @@ ROOT="$(cd "$HERE/../.." && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function ${EXTRA_HIPCC_FLAGS}"
 OUT="${BSVD_OUT:-$ROOT/bsvd_amd/libbsvd_hip.so}"
-OBJ="$HERE/obj${BSVD_OBJ_SUFFIX:-}"
+# objects live outside the package: build/obj (product), build/obj_ab<i> (tools/build_ab.sh variants)
+OBJ="$ROOT/build/obj${BSVD_OBJ_SUFFIX:-}"
 mkdir -p "$OBJ"
 pids=()
 for src in conv3x3_mfma conv3x3_wino conv3x3_winox conv3x3_edge_f32 bsvd_abi; do
   if [ ! -f "$OBJ/$src.o" ] || [ "$HERE/$src.hip" -nt "$OBJ/$src.o" ] || \
      [ "$HERE/bsvd_internal.h" -nt "$OBJ/$src.o" ] || [ "$HERE/wino_forms.h" -nt "$OBJ/$src.o" ] || [ "$ROOT/include/bsvd_hip.h" -nt "$OBJ/$src.o" ] || \
      [ "$(cat "$OBJ/$src.flags" 2>/dev/null)" != "$FLAGS" ]; then
-    ( $HIPCC $FLAGS -c "$HERE/$src.hip" -o "$OBJ/$src.o" && echo "$FLAGS" > "$OBJ/$src.flags" ) &
+    # conv3x3_winox: no SLP vectorizer (it turns the transform's fma_mix forms into convert + packed-fp32 math, see dec_pair)
+    XF=""; [ "$src" = conv3x3_winox ] && XF="-fno-slp-vectorize"
+    ( $HIPCC $FLAGS $XF -c "$HERE/$src.hip" -o "$OBJ/$src.o" && echo "$FLAGS" > "$OBJ/$src.flags" ) &
     pids+=($!)
   fi
 done

@@ -21,8 +21,8 @@
 //     (patch row, group, 4 channels) loads A pixels x (8 B hi + 8 B lo) with branch-free raw buffer loads (out of range = 0 =
 //     the conv's zero padding), decodes to fp32, applies BT, re-splits every value into an fp16 pair, writes 2 A ds_write_b64.
 //     The temporal-shift gather is a per-chunk source select of this load, as in the direct kernel.
-//   * weight operand U[xi][ky]: transformed in double and split at pack time (bsvd_pack_weights_wino), L2 -> VGPRs through a
-//     3-slot register ring, two steps ahead.
+//   * weight operand U[xi][ky]: transformed in double and split at pack time (bsvd_pack_weights_wino), L2 -> VGPRs, the three
+//     slabs of a chunk requested at the end of the previous chunk's MFMA steps.
 //   * the waves that share a SIMD (wave w, w + 4, w + 8) run the chunk's two phases -- MFMA steps / transform of the next
 //     chunk -- in opposite order, so that one's VALU and memory waits sit under the other's MFMAs.
 // Epilogue: two rounds (MFMA tiles 0-1, 2-3).  Every wave publishes its accumulator tiles in LDS ([block][xi][4 regs][lane],
@@ -35,8 +35,29 @@
 #include "wino_forms.h"
 
 #define BSVD_WX_OOB 0x7fffffffu
+#ifndef BSVD_WX_ILV
+#define BSVD_WX_ILV 0      // 1: the transform of the next chunk is interleaved INTO each wave's own MFMA stream (sched_group_barrier pipeline) instead of
+                           //    running as a separate phase: a wave that streams MFMAs leaves the other wave of its SIMD about one VALU issue per MFMA
+                           //    (measured: phases of the two waves do not overlap, their times add), its own fillers ride in the MFMA's shadow
+#endif
+#ifndef BSVD_WX_ILV_VALU
+#define BSVD_WX_ILV_VALU 2 // VALU instructions per MFMA in the interleave pipeline
+#endif
+#ifndef BSVD_WX_ABL
+#define BSVD_WX_ABL 0      // TIMING-ONLY ablations (results wrong): 1 no transform in the K loop, 2 no MFMA steps, 4 no epilogue finish, 8 no chunk barrier, 16 transform without its global loads, 32 transform without its LDS stores
+#endif
 
 namespace bsvd {
+
+#ifdef BSVD_WX_TL
+// Measurement build (tools/debug/wx_timeline.py): per workgroup and wave, shader cycles (s_memtime) summed over the K loop per
+// section -- 0 first transform slot, 1 MFMA steps, 2 second transform slot, 3 chunk barrier -- plus 4 prologue, 5 epilogue, 6 total.
+#define BSVD_WX_TL_SLOTS 4096
+__device__ unsigned long long g_wx_tl[BSVD_WX_TL_SLOTS][12][8];
+#define WXT_NOW() ({ unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_; })
+#else
+#define WXT_NOW() 0ull
+#endif
 
 namespace {
 
@@ -73,7 +94,8 @@ struct XCfg {
     static constexpr int LDS_BYTES = 2 * V_BUF > XCH_BYTES ? 2 * V_BUF : XCH_BYTES;
     static constexpr int NPART = NW / NBP >= 2 ? 2 : 1;          // finishers per block (column ranges)
     static_assert(LDS_BYTES <= 160 * 1024 && NW * 64 <= 1024 && NW % 4 == 0 && NW >= NBP, "");
-    static constexpr int NPH = NW / 4;            // waves per SIMD = phases of the chunk schedule
+    static constexpr int WGS = LDS_BYTES <= 80 * 1024 && NW == 4 ? 2 : 1;      // workgroups per CU
+    static constexpr int NPH = NW / 4 > 1 ? NW / 4 : 2;   // waves per SIMD = phases of the chunk schedule (4-wave workgroups: waves 0-1 / 2-3)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *ptr, unsigned bytes)
@@ -89,21 +111,71 @@ __device__ __forceinline__ u32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned vo
     return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
 
+// One-instruction forms of the two conversions the transform is made of (v_fma_mix*: fp16 sources read in place, one rounding).
+// Written as plain fma()s against OPAQUE +-1.0 scalars so that (a) the compiler cannot fold  x * 1 + y  back into convert + add and
+// selects v_fma_mix_f32 / v_fma_mixlo_f16 / v_fma_mixhi_f16 itself (this file is built with -fno-slp-vectorize: with the SLP
+// vectorizer on it prefers v_cvt + v_pk_fma_f32), and (b) the instructions stay visible to the scheduler (sched_group_barrier does
+// not see inline asm):
+//   decode   d = (float)hi + (float)lo                      -> v_fma_mix_f32   d, hi.h[SEL], 1.0, lo.h[SEL]
+//   residual lo' = fp16(v - (float)hi') for a pair (v0, v1) -> v_fma_mixlo_f16 / v_fma_mixhi_f16  (v - hi' is exact in fp32, so this is
+//            bit for bit the (_Float16)(v - (float)hi') of the plain form: 3 instructions per value there, 1 here)
+struct MixConst { float one, mone; };
+template <int SEL>
+__device__ __forceinline__ float dec_pair(unsigned h, unsigned l, const MixConst &k)
+{
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    const f16x2_t hv = __builtin_bit_cast(f16x2_t, h), lv = __builtin_bit_cast(f16x2_t, l);
+    return __builtin_fmaf((float)hv[SEL], k.one, (float)lv[SEL]);
+}
+__device__ __forceinline__ void split_pair(float v0, float v1, unsigned &hp, unsigned &lp, const MixConst &k)
+{
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    static_assert(BSVD_TUNE_LO_BITS >= 10, "the mixed-precision split keeps all bits of the lo halves");
+    const f16x2_t hv = {(_Float16)v0, (_Float16)v1};                                  // v_cvt_pk_f16_f32 (round to nearest even)
+    const f16x2_t lv = {(_Float16)__builtin_fmaf((float)hv[0], k.mone, v0), (_Float16)__builtin_fmaf((float)hv[1], k.mone, v1)};
+    hp = __builtin_bit_cast(unsigned, hv);
+    lp = __builtin_bit_cast(unsigned, lv);
+}
+
 struct XChunkSrc {         // wave-uniform source of one 16-channel chunk (temporal-shift gather: next / previous / this frame)
     __amdgpu_buffer_rsrc_t rs;
     unsigned ps4, soff;
 };
+// The three temporal sources of a frame as plain scalars.  (chunk_src as a lambda over ready-made descriptors made hipcc keep a
+// table of them -- and, one nesting level later, the kernel parameters -- in private memory: a free function over a POD passed by
+// value, scalar selects, the 128-bit descriptor built at the point of use.)
+struct XSources {
+    const float *cur, *prv, *nxt;
+    unsigned cur_bytes, prev_bytes, next_bytes, cur_ps4, prev_ps4, next_ps4;
+    int prev_co, next_co, fold, ncb, zs_a, zs_b, zs_c;      // zs_*: zero-chunk skip (live -> full chunk index)
+};
+__device__ __forceinline__ int x_full_chunk(const XSources &s, int cbl) { return cbl + s.zs_a + (cbl >= s.zs_b ? s.zs_c : 0); }
+__device__ __forceinline__ XChunkSrc x_chunk_src(const XSources s, int cbl)      // cbl: LIVE chunk index; beyond the last: zero-size descriptor
+{
+    XChunkSrc c;
+    const int c0 = x_full_chunk(s, cbl) * 16;
+    const bool isn = c0 < s.fold, isp = !isn && c0 < 2 * s.fold;
+    const float *base = isn ? s.nxt : isp ? s.prv : s.cur;
+    unsigned bytes = isn ? s.next_bytes : isp ? s.prev_bytes : s.cur_bytes;
+    if (cbl >= s.ncb) bytes = 0u;
+    c.rs = make_rsrc(base, bytes);
+    c.ps4 = isn ? s.next_ps4 : isp ? s.prev_ps4 : s.cur_ps4;
+    c.soff = (unsigned)(isn ? s.next_co + c0 : isp ? s.prev_co + c0 - s.fold : c0) * 4u;
+    return c;
+}
 
 }  // namespace
 
 template <int M, int NH, int NTW>
-__global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), 1) void winox_kernel(const ConvParams p)
+__global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), (XCfg<M, NH, NTW>::NW / 4 * XCfg<M, NH, NTW>::WGS)) void winox_kernel(const ConvParams p)
 {
     using C = XCfg<M, NH, NTW>;
     using F = WinoForm<M>;
     constexpr int A = C::A;
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
 
+    [[maybe_unused]] unsigned long long tl_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    [[maybe_unused]] const unsigned long long tl_start = WXT_NOW();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -142,21 +214,12 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), 1) void winox_kernel(
         ncb -= zs_a + zs_c;
     }
     const unsigned hw = (unsigned)p.H * (unsigned)p.W;
-    const __amdgpu_buffer_rsrc_t rs_cur = make_rsrc(cur, hw * p.Cin * 4u);
-    const __amdgpu_buffer_rsrc_t rs_prev = make_rsrc(prv ? prv : cur, prv ? hw * prev_ps * 4u : 0u);
-    const __amdgpu_buffer_rsrc_t rs_next = make_rsrc(nxt ? nxt : cur, nxt ? hw * next_ps * 4u : 0u);
-    const __amdgpu_buffer_rsrc_t rs_none = make_rsrc(cur, 0u);
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)p.Cin * (unsigned)(3 * A) * (unsigned)p.Cout * 4u);
-    auto full_chunk = [&](int cbl) { return cbl + zs_a + (cbl >= zs_b ? zs_c : 0); };
-    auto chunk_src = [&](int cbl) {            // cbl: LIVE chunk index
-        XChunkSrc c;
-        if (cbl >= ncb) { c.rs = rs_none; c.ps4 = 0; c.soff = 0; return c; }
-        const int c0 = full_chunk(cbl) * 16;
-        if (c0 < p.fold)          { c.rs = rs_next; c.ps4 = next_ps * 4u; c.soff = (next_co + c0) * 4u; }
-        else if (c0 < 2 * p.fold) { c.rs = rs_prev; c.ps4 = prev_ps * 4u; c.soff = (prev_co + c0 - p.fold) * 4u; }
-        else                      { c.rs = rs_cur;  c.ps4 = p.Cin * 4u;   c.soff = c0 * 4u; }
-        return c;
-    };
+    XSources S;
+    S.cur = cur; S.prv = prv ? prv : cur; S.nxt = nxt ? nxt : cur;
+    S.cur_bytes = hw * p.Cin * 4u; S.prev_bytes = prv ? hw * prev_ps * 4u : 0u; S.next_bytes = nxt ? hw * next_ps * 4u : 0u;
+    S.cur_ps4 = p.Cin * 4u; S.prev_ps4 = prev_ps * 4u; S.next_ps4 = next_ps * 4u;
+    S.prev_co = prev_co; S.next_co = next_co; S.fold = p.fold; S.ncb = ncb; S.zs_a = zs_a; S.zs_b = zs_b; S.zs_c = zs_c;
 
     // ---- weights of this wave's position: rows of the MFMA's A operand = output channels (conv3x3_mfma.hip: `chan`)
     const int rrow = (li & 3) + 4 * (li >> 3);
@@ -167,10 +230,10 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), 1) void winox_kernel(
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) vb[nt] = nb0 + 32 * nt < p.Cout ? (unsigned)(lh * p.Cout + nb0 + 32 * nt) * 16u : BSVD_WX_OOB;
     const int nsteps = ncb * 3;
-    auto load_b = [&](int step, f32x4 (&b)[NTW][2]) {     // step = live chunk * 3 + ky
+    auto load_b = [&](int step, f32x4 (&b)[NTW][2]) __attribute__((always_inline)) {     // step = live chunk * 3 + ky
         step = step < nsteps ? step : nsteps - 1;
         const int cbl = step / 3, ky = step - 3 * cbl;
-        const unsigned so = (unsigned)((full_chunk(cbl) * A + xi) * 3 + ky) * slab_bytes;
+        const unsigned so = (unsigned)((x_full_chunk(S, cbl) * A + xi) * 3 + ky) * slab_bytes;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             b[nt][0] = buf_load4(rs_w, vb[nt], so);
@@ -178,70 +241,144 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), 1) void winox_kernel(
         }
     };
 
-    // ---- transform items: E = row * 32 + qb * 16 + group * 2 + half -> 4 channels c4 = 2 qb + half of patch slot (row, group);
-    //      16 consecutive lanes write 128 contiguous LDS bytes
-    auto transform_item = [&](const XChunkSrc &c, unsigned char *vbuf, int E, bool active) {
-        const int row = E >> 5, qb = (E >> 4) & 1, g = (E >> 1) & 7, half = E & 1;
-        const int gy = oy0 - 1 + row, gx0 = ox0 - 1 + M * g;
-        const bool row_ok = active && gy >= 0 && gy < p.H;
-        const unsigned pix0 = (unsigned)(gy * p.W + gx0);
-        const unsigned c4off = (unsigned)(qb * 16 + half * 8);
-        u32x2 rh[A], rl[A];
+    // ---- transform items.  CH channels of one patch slot (row, group) per item:
+    //        CH = 4 (768-thread workgroups): E = row * 32 + qb * 16 + group * 2 + half        -> channels 8 qb + 4 half .. + 3, 8-byte loads
+    //        CH = 2 (512-thread workgroups): E = row * 64 + qb * 32 + group * 4 + pr          -> channels 8 qb + 2 pr, + 1,     4-byte loads
+    //      (consecutive lanes cover consecutive bytes of a slot, then consecutive slots: 4-byte LDS stores of 32 lanes hit 32 banks.)
+    //      An item is LOADED one chunk before it is FINISHED (decode, BT, re-split, LDS stores): the raw registers ride through the
+    //      MFMA steps in between, so that no wave ever waits for the activation tensor (1-3 us away) with nothing else to issue.
+    //      Rows outside the image need no mask -- their byte offsets fall outside the buffer descriptor (negative rows wrap to > 2 GiB),
+    //      and an inactive lane starts from the out-of-range sentinel; only columns are compared.
+    MixConst mixk = {1.0f, -1.0f};
+    asm volatile("" : "+s"(mixk.one), "+s"(mixk.mone));         // opaque: see dec_pair / split_pair
+    constexpr int CH = C::NTHREADS == 512 ? 2 : 4;
+    constexpr int NDW = CH / 2;                                   // dwords per pixel and part
+    struct Raw { unsigned h[A][NDW], l[A][NDW]; };
+    auto item_load = [&](const XChunkSrc &c, int E, bool active, Raw &r) __attribute__((always_inline)) {
+        int row, qb, g, sub;
+        if constexpr (CH == 4) { row = E >> 5; qb = (E >> 4) & 1; g = (E >> 1) & 7; sub = (E & 1) * 8; }
+        else                   { row = E >> 6; qb = (E >> 5) & 1; g = (E >> 2) & 7; sub = (E & 3) * 4; }
+        const int gx0 = ox0 - 1 + M * g;
+        const unsigned base = active ? (unsigned)((oy0 - 1 + row) * p.W + gx0) * c.ps4 + (unsigned)(qb * 16 + sub) : BSVD_WX_OOB;
 #pragma unroll
         for (int i = 0; i < A; ++i) {
-            const int gx = gx0 + i;
-            const bool ok = row_ok && gx >= 0 && gx < p.W;
-            const unsigned voff = ok ? (pix0 + (unsigned)i) * c.ps4 + c4off : BSVD_WX_OOB;
-            rh[i] = buf_load2(c.rs, voff, c.soff);
-            rl[i] = buf_load2(c.rs, voff, c.soff + 32u);
-        }
-        // two channels at a time (the fp16 results of a pair are one dword per position and part): fewer live registers than
-        // four channels + 8-byte stores, at the price of 4-byte LDS stores (2-way bank aliasing between the qb planes: free)
-        unsigned char *dst = vbuf + qb * C::PLANE + (row * 8 + g) * 16 + half * 8;
+            const unsigned voff = (unsigned)(gx0 + i) < (unsigned)p.W ? base + (unsigned)i * c.ps4 : BSVD_WX_OOB;
+            if constexpr (BSVD_WX_ABL & 16) {
 #pragma unroll
-        for (int cp = 0; cp < 2; ++cp) {
-            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-            f16x2 vh[A], vl[A];
+                for (int k = 0; k < NDW; ++k) { r.h[i][k] = 0x3c003c00u ^ (voff & 0x00ff00ffu); r.l[i][k] = 0x1c001c00u; }
+            } else if constexpr (CH == 4) {
+                const u32x2 hv = buf_load2(c.rs, voff, c.soff), lv = buf_load2(c.rs, voff, c.soff + 32u);
+                r.h[i][0] = hv[0]; r.h[i][NDW - 1] = hv[1]; r.l[i][0] = lv[0]; r.l[i][NDW - 1] = lv[1];
+            } else {
+                r.h[i][0] = __builtin_amdgcn_raw_buffer_load_b32(c.rs, voff, c.soff, 0);
+                r.l[i][0] = __builtin_amdgcn_raw_buffer_load_b32(c.rs, voff, c.soff + 32u, 0);
+            }
+        }
+    };
+    auto item_finish = [&](unsigned char *vbuf, int E, bool active, const Raw &r) __attribute__((always_inline)) {
+        int row, qb, g, sub;
+        if constexpr (CH == 4) { row = E >> 5; qb = (E >> 4) & 1; g = (E >> 1) & 7; sub = (E & 1) * 8; }
+        else                   { row = E >> 6; qb = (E >> 5) & 1; g = (E >> 2) & 7; sub = (E & 3) * 4; }
+        unsigned char *dst = vbuf + qb * C::PLANE + (row * 8 + g) * 16 + sub;
+#pragma unroll
+        for (int cp = 0; cp < NDW; ++cp) {            // a channel pair = one dword per position and part
+            float v[2][A];
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
-                const int ch = 2 * cp + cc;
-                float d[A], v[A];
-                __builtin_amdgcn_sched_barrier(0);        // one channel at a time: the scheduler otherwise decodes all four first (64 live floats at M = 6)
+                float d[A];
+                if constexpr (BSVD_WX_ILV != 1) __builtin_amdgcn_sched_barrier(0);    // one channel at a time (the scheduler otherwise decodes everything first: 64 live floats at M = 6)
 #pragma unroll
-                for (int i = 0; i < A; ++i) {
-                    const f16x4 h = __builtin_bit_cast(f16x4, rh[i]), l = __builtin_bit_cast(f16x4, rl[i]);
-                    d[i] = (float)h[ch] + (float)l[ch];
-                }
-                F::input(d, v);
-#pragma unroll
-                for (int i = 0; i < A; ++i) {
-                    const _Float16 hv = (_Float16)v[i];
-                    vh[i][cc] = hv;
-                    vl[i][cc] = lo_keep((_Float16)(v[i] - (float)hv));
-                }
+                for (int i = 0; i < A; ++i) d[i] = cc ? dec_pair<1>(r.h[i][cp], r.l[i][cp], mixk) : dec_pair<0>(r.h[i][cp], r.l[i][cp], mixk);
+                F::input(d, v[cc]);
             }
-            if (active) {
 #pragma unroll
-                for (int i = 0; i < A; ++i) {
-                    *reinterpret_cast<unsigned *>(dst + i * 4 * C::PLANE + cp * 4) = __builtin_bit_cast(unsigned, vh[i]);
-                    *reinterpret_cast<unsigned *>(dst + i * 4 * C::PLANE + 2 * C::PLANE + cp * 4) = __builtin_bit_cast(unsigned, vl[i]);
+            for (int i = 0; i < A; ++i) {
+                unsigned hp, lp;
+                split_pair(v[0][i], v[1][i], hp, lp, mixk);
+                if (active && !((BSVD_WX_ABL & 32) && hp == 0x12345678u)) {
+                    *reinterpret_cast<unsigned *>(dst + i * 4 * C::PLANE + cp * 4) = hp;
+                    *reinterpret_cast<unsigned *>(dst + i * 4 * C::PLANE + 2 * C::PLANE + cp * 4) = lp;
                 }
             }
         }
     };
-    // the workgroup's share of one chunk's 576 items; `rot` rotates the wave that takes the 64 left-over items (rows 16, 17)
-    auto transform_chunk = [&](const XChunkSrc &c, unsigned char *vbuf, int rot) {
-        // the item geometry is re-derived per chunk from an opaque copy of the lane id: hoisted out of the K loop it would pin
-        // ~30 registers (A offsets, masks, store addresses) that the accumulators need
+    // The same work in 4 NDW stages with the transformed values carried between them (ILV = 2: a stage per MFMA step):
+    //   stage 4 cp + 0 | 1: decode + BT of channel 2 cp + 0 | 1;  stage 4 cp + 2 | 3: re-split + LDS stores of positions [0, A/2) | [A/2, A)
+    struct Mid { float v[2][A]; };
+    auto item_stage = [&](unsigned char *vbuf, int E, bool active, const Raw &r, Mid &m, auto st_) __attribute__((always_inline)) {
+        constexpr int ST = decltype(st_)::value, cp = ST / 4, q = ST % 4;
+        if constexpr (q < 2) {
+            float d[A];
+#pragma unroll
+            for (int i = 0; i < A; ++i) d[i] = q ? dec_pair<1>(r.h[i][cp], r.l[i][cp], mixk) : dec_pair<0>(r.h[i][cp], r.l[i][cp], mixk);
+            F::input(d, m.v[q]);
+        } else {
+            int row, qb, g, sub;
+            if constexpr (CH == 4) { row = E >> 5; qb = (E >> 4) & 1; g = (E >> 1) & 7; sub = (E & 1) * 8; }
+            else                   { row = E >> 6; qb = (E >> 5) & 1; g = (E >> 2) & 7; sub = (E & 3) * 4; }
+            unsigned char *dst = vbuf + qb * C::PLANE + (row * 8 + g) * 16 + sub;
+#pragma unroll
+            for (int i = (q - 2) * (A / 2); i < (q - 1) * (A / 2); ++i) {
+                unsigned hp, lp;
+                split_pair(m.v[0][i], m.v[1][i], hp, lp, mixk);
+                if (active) {
+                    *reinterpret_cast<unsigned *>(dst + i * 4 * C::PLANE + cp * 4) = hp;
+                    *reinterpret_cast<unsigned *>(dst + i * 4 * C::PLANE + 2 * C::PLANE + cp * 4) = lp;
+                }
+            }
+        }
+    };
+    // A wave's items of chunk `cc` (live index).  768 threads: one 4-channel item on 48 lanes of every wave (576 items).  512 threads:
+    // two 2-channel items per lane (1024 of 1152) + 128 left over (rows 16, 17), one more item for the two waves cc % NW, (cc + 1) % NW.
+    // 256 threads: two 4-channel items per lane (512 of 576) + 64 left over, one more item for the wave cc % NW.
+    // BAL (the interleaved schedule): no rotating waves -- the left-over items are dealt 16 lanes to every wave as a third, partial item
+    // (a quarter of its lanes active: more instructions per wave, but every wave the same, and all of it in the MFMAs' shadow; a rotating
+    // wave's extra item held the chunk barrier up for ~2000 cycles of 7900)
+    constexpr bool BAL = BSVD_WX_ILV == 2 && C::NTHREADS != 768;
+    constexpr int NMAIN = C::NTHREADS == 768 ? 1 : BAL ? 3 : 2;
+    constexpr int NROT = (C::NTHREADS == 768 || BAL) ? 0 : C::NTHREADS == 512 ? 2 : 1;      // 64-item blocks left over per chunk
+    constexpr int ROT0 = 2 * C::NTHREADS;                                                     // first left-over item
+    static_assert(C::NTHREADS == 768 || C::NTHREADS == 512 || C::NTHREADS == 256, "item map");
+    auto lane_id = [&]() __attribute__((always_inline)) {      // opaque per use: the item geometry is re-derived per chunk -- hoisted out of the K loop it pins ~30 registers
         int tl = lane;
         asm volatile("" : "+v"(tl));
-        if constexpr (C::NTHREADS == 768) {
-            transform_item(c, vbuf, wid * 48 + tl, tl < 48);
-        } else {
-            static_assert(C::NTHREADS == 512 || C::NTHREADS == 256, "item map");
+        return tl;
+    };
+    auto main_E = [&](int k, int tl) __attribute__((always_inline)) {
+        return C::NTHREADS == 768 ? wid * 48 + tl : k < 2 ? k * C::NTHREADS + wid * 64 + tl : ROT0 + wid * (64 * (C::NTHREADS == 512 ? 2 : 1) / C::NW) + tl;
+    };
+    auto main_active = [&](int k, int tl) __attribute__((always_inline)) {
+        return C::NTHREADS == 768 ? tl < 48 : k < 2 ? true : tl < 64 * (C::NTHREADS == 512 ? 2 : 1) / C::NW;
+    };
+    auto rot_slot = [&](int cc) __attribute__((always_inline)) {                // 0 / 1: this wave takes left-over block 0 / 1 of chunk cc, -1: none
+        if constexpr (NROT == 0) return -1;
+        const int d = (wid - cc % C::NW + C::NW) % C::NW;
+        return d < NROT ? d : -1;
+    };
+    // PP raw register sets: chunk cc's items live in set cc % PP.  PP = 2 where the registers are there (F(2,3)): an item is then
+    // requested TWO chunks before it is finished
+    constexpr int PP = (M == 2 && C::NTHREADS == 512 && BSVD_WX_ILV != 2) ? 2 : 1;
+    Raw raw[PP][NMAIN], raw_rot[PP];
+    using PAll = std::integral_constant<int, 3>;     // part_: 1 the lanes' main items, 2 the rotating left-over block, 3 both
+    auto chunk_load = [&](int cc, int SET, auto part_, int tl) __attribute__((always_inline)) {
+        const XChunkSrc c = x_chunk_src(S, cc);       // beyond the last chunk: zero-size descriptor, zeros, never read
+        if constexpr (decltype(part_)::value & 1) {
 #pragma unroll
-            for (int r = 0; r < 512 / C::NTHREADS; ++r) transform_item(c, vbuf, r * C::NTHREADS + wid * 64 + tl, true);
-            if (wid == rot % C::NW) transform_item(c, vbuf, 512 + tl, true);
+        for (int k = 0; k < NMAIN; ++k) item_load(c, main_E(k, tl), main_active(k, tl), raw[SET][k]);
+        }
+        if constexpr (NROT > 0 && (decltype(part_)::value & 2)) {
+            const int rs = rot_slot(cc);
+            if (rs >= 0) item_load(c, ROT0 + rs * 64 + tl, true, raw_rot[SET]);
+        }
+    };
+    auto chunk_finish = [&](int cc, unsigned char *vbuf, int SET, auto part_, int tl) __attribute__((always_inline)) {
+        if constexpr (decltype(part_)::value & 1) {
+#pragma unroll
+        for (int k = 0; k < NMAIN; ++k) item_finish(vbuf, main_E(k, tl), main_active(k, tl), raw[SET][k]);
+        }
+        if constexpr (NROT > 0 && (decltype(part_)::value & 2)) {
+            const int rs = rot_slot(cc);
+            if (rs >= 0) item_finish(vbuf, ROT0 + rs * 64 + tl, true, raw_rot[SET]);
         }
     };
 
@@ -258,25 +395,45 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), 1) void winox_kernel(
     f32x4 bring[3][NTW][2];
     load_b(0, bring[0]);
     load_b(1, bring[1]);
-    transform_chunk(chunk_src(0), xsm, 0);
+    load_b(2, bring[2]);
+    chunk_load(0, 0, PAll{}, lane);
+    chunk_finish(0, xsm, 0, PAll{}, lane);
+    chunk_load(1, PP - 1, PAll{}, lane);
+    if constexpr (PP == 2) chunk_load(2, 0, PAll{}, lane);
     __syncthreads();
 
     const unsigned a_lane = (unsigned)(xi * 4 * C::PLANE + lh * C::PLANE + li * 16);
-    const int phase = (wid >> 2) % C::NPH;          // waves w, w + 4, (w + 8) share a SIMD
-    for (int cb = 0; cb < ncb; ++cb) {
+#ifndef BSVD_WX_PHASE
+#define BSVD_WX_PHASE 0    // which waves run the chunk's phases in opposite order: 0 (wid >> 2), 1 wid, 2 (wid >> 1)   (A/B: who shares a SIMD?)
+#endif
+    const int phase = C::NW == 4 ? (wid >> 1) : (BSVD_WX_PHASE == 0 ? (wid >> 2) : BSVD_WX_PHASE == 1 ? wid : (wid >> 1)) % C::NPH;
+    // (the loop body is written out in the loop, not as a lambda: one more level of by-reference closure nesting and hipcc no longer
+    //  promotes the captured locals -- kernel parameters, pointers, the raw sets -- out of private memory)
+    [[maybe_unused]] const unsigned long long tl_loop = WXT_NOW();
+    for (int cb0 = 0; cb0 < ncb; cb0 += PP) {
+#pragma unroll
+    for (int u = 0; u < PP; ++u) {
+        const int cb = cb0 + u;
+        if (cb >= ncb) break;
+        const int setv = PP == 2 ? ((u + 1) & 1) : 0;          // the raw set of chunk cb + 1 (a constant after unrolling)
         const unsigned char *pcur = xsm + (cb & 1) * C::V_BUF + a_lane;
         unsigned char *pnext = xsm + ((cb + 1) & 1) * C::V_BUF;
-        auto mfma_phase = [&]() {
-            static_for<0, 3>([&](auto k_) {
-                constexpr int KY = decltype(k_)::value;
-                load_b(cb * 3 + KY + 2, bring[(KY + 2) % 3]);
+        auto mfma_phase = [&]() __attribute__((always_inline)) {
+            f32x4 afr[2][2];          // fragments one (ky, mt) step ahead, see the interleaved schedule
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) afr[0][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE);
+            static_for<0, 12>([&](auto k_) __attribute__((always_inline)) {
+                constexpr int S_ = decltype(k_)::value, KY = S_ / 4, mt = S_ % 4;
                 const f32x4 (&b)[NTW][2] = bring[KY];
+                {
+                    if constexpr (S_ < 11) {
+                        constexpr int KY1 = (S_ + 1) / 4, mt1 = (S_ + 1) % 4;
 #pragma unroll
-                for (int mt = 0; mt < C::MT; ++mt) {
-                    f32x4 a[2];
-#pragma unroll
-                    for (int pt = 0; pt < 2; ++pt)
-                        a[pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE + (4 * mt + KY) * 128);
+                        for (int pt = 0; pt < 2; ++pt)
+                            afr[(S_ + 1) & 1][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE + (4 * mt1 + KY1) * 128);
+                    }
+                    const f32x4 (&a)[2] = afr[S_ & 1];
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int pass = 0; pass < 3; ++pass)
 #pragma unroll
@@ -288,22 +445,143 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), 1) void winox_kernel(
                         }
                 }
             });
+            // the weights of the NEXT chunk, all three slabs, requested here: a wave's loads return in issue order, so every load a
+            // phase consumes must have been issued before the activation loads (1-3 us away) that the following phase waits for --
+            // issue order = consumption order, and nobody ever waits for the activation tensor on behalf of a weight slab
+            static_for<0, 3>([&](auto k_) __attribute__((always_inline)) { load_b((cb + 1) * 3 + decltype(k_)::value, bring[decltype(k_)::value]); });
         };
-        const XChunkSrc cn = chunk_src(cb + 1);          // beyond the last chunk: zero-size descriptor, zeros, never read
+        // transform step of this iteration: finish chunk cb + 1 (requested PP iterations ago) into the other buffer, request chunk cb + 1 + PP
+#ifndef BSVD_WX_PRIO
+#define BSVD_WX_PRIO 0     // s_setprio level of the transform phase (the MFMA steps run at 0): a wave streaming MFMAs wins the VALU arbitration every cycle
+#endif
+        auto xform = [&]() __attribute__((always_inline)) {
+            if (BSVD_WX_PRIO) __builtin_amdgcn_s_setprio(BSVD_WX_PRIO);
+            const int tl = lane_id();
+            chunk_finish(cb + 1, pnext, setv, PAll{}, tl);
+            chunk_load(cb + 1 + PP, setv, PAll{}, tl);
+            if (BSVD_WX_PRIO) __builtin_amdgcn_s_setprio(0);
+        };
         // (one copy of the MFMA steps between two conditional transforms: an if / else with the phases in opposite orders made the
         //  register allocator carry the accumulators in two register sets and spill 60-260 registers)
-        if (phase != 0) transform_chunk(cn, pnext, cb + 1);
+        if constexpr (BSVD_WX_ILV == 2) {
+            // Manual coarse interleave, pinned with scheduling fences: the 12 (ky, mt) steps of 3 NTW MFMAs each, and behind every step one
+            // slot of the wave's OWN transform work.  (A wave streaming MFMAs leaves the other wave of its SIMD about one VALU issue per MFMA
+            // -- phases of different waves do not overlap, their times add; a wave's own fillers issue in its MFMAs' shadow.)
+            //   PP = 2 (items requested two chunks ahead): stage i behind step i, the requests behind steps 8, 9
+            //   PP = 1: two stages behind each of the first steps, the requests right after them -- the longest way to the next chunk
+            // Stage order: the decode + BT stages of every (item, channel pair) first -- an item's raw registers are free after them and
+            // its request for the chunk after goes out in the next slot, a whole iteration before it is decoded --, then the re-split +
+            // store stages.  SPS stages per slot so that everything fits the 12 slots.
+            using PRot = std::integral_constant<int, 2>;
+            constexpr int NU = NDW * NMAIN;                  // (item, channel pair) units: unit = k * NDW + cp
+            constexpr int NST = 4 * NU;
+            constexpr int SPS = (NST + 11) / 12;             // stages per slot
+            static_assert(PP == 1, "the interleaved schedule requests an item one iteration ahead");
+            [[maybe_unused]] const unsigned long long t0 = WXT_NOW();
+            const int tl = lane_id();
+            const XChunkSrc cl = x_chunk_src(S, cb + 2);
+            Mid mid[NU];
+            // the group fragments of step s + 1 are requested in front of step s's MFMAs (two register sets): an LDS round trip per
+            // step was a third of the MFMA steps' time (52 cycles per MFMA instead of 32 with nothing else on the SIMD)
+            f32x4 afr[2][2];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) afr[0][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE);
+            static_for<0, 12>([&](auto s_) __attribute__((always_inline)) {
+                constexpr int S_ = decltype(s_)::value, KY = S_ / 4, mt = S_ % 4;
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const f32x4 (&b)[NTW][2] = bring[KY];
+                    if constexpr (S_ < 11) {
+                        constexpr int KY1 = (S_ + 1) / 4, mt1 = (S_ + 1) % 4;
+#pragma unroll
+                        for (int pt = 0; pt < 2; ++pt)
+                            afr[(S_ + 1) & 1][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE + (4 * mt1 + KY1) * 128);
+                    }
+                    const f32x4 (&a)[2] = afr[S_ & 1];
+#pragma unroll
+                    for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt) {
+                            const f16x8 bv = __builtin_bit_cast(f16x8, b[nt][pass == 1 ? 1 : 0]);
+                            const f16x8 av = __builtin_bit_cast(f16x8, a[pass == 0 ? 1 : 0]);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv, av, acc[mt][nt], 0, 0, 0);
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // the slot behind this step: stage index G = S_ * SPS + j;  G < 2 NU: decode stage G % 2 of unit G / 2;  else split stage
+                static_for<0, SPS>([&](auto j_) __attribute__((always_inline)) {
+                    constexpr int G = S_ * SPS + decltype(j_)::value;
+                    if constexpr (G < 2 * NU) {
+                        constexpr int un = G / 2, k = un / NDW, cp = un % NDW;
+                        item_stage(pnext, main_E(k, tl), main_active(k, tl), raw[setv][k], mid[un], std::integral_constant<int, 4 * cp + G % 2>{});
+                        // last decode stage of item k: its registers take the request for the chunk after next
+                        if constexpr (cp == NDW - 1 && G % 2 == 1) item_load(cl, main_E(k, tl), main_active(k, tl), raw[setv][k]);
+                    } else if constexpr (G < NST) {
+                        constexpr int H = G - 2 * NU, un = H / 2, k = un / NDW, cp = un % NDW;
+                        item_stage(pnext, main_E(k, tl), main_active(k, tl), raw[setv][k], mid[un], std::integral_constant<int, 4 * cp + 2 + H % 2>{});
+                    }
+                });
+                if constexpr (mt == 3) load_b((cb + 1) * 3 + KY, bring[KY]);      // this slab's last use was the step above
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            [[maybe_unused]] const unsigned long long t2 = WXT_NOW();
+            chunk_finish(cb + 1, pnext, setv, PRot{}, tl);
+            chunk_load(cb + 1 + PP, setv, PRot{}, tl);
+            [[maybe_unused]] const unsigned long long t3 = WXT_NOW();
+            if (!(BSVD_WX_ABL & 8)) __syncthreads();
+#ifdef BSVD_WX_TL
+            { const unsigned long long t4 = WXT_NOW(); tl_acc[1] += t2 - t0; tl_acc[2] += t3 - t2; tl_acc[3] += t4 - t3; }
+#endif
+            continue;
+        }
+        if constexpr (BSVD_WX_ILV == 1) {
+            using PMain = std::integral_constant<int, 1>;
+            using PRot = std::integral_constant<int, 2>;
+            [[maybe_unused]] const unsigned long long t0 = WXT_NOW();
+            const int tl = lane_id();            // (a volatile asm: a scheduling-region boundary -- once, in front of the region)
+            __builtin_amdgcn_sched_barrier(0);
+            // one scheduling region: MFMA steps + this lane's main items of the next chunk + the requests for the chunk after
+            chunk_finish(cb + 1, pnext, setv, PMain{}, tl);
+            mfma_phase();
+            chunk_load(cb + 1 + PP, setv, PMain{}, tl);
+            static_for<0, 3 * C::MT * 3 * NTW>([&](auto) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, BSVD_WX_ILV_VALU, 0);      // VALU
+                __builtin_amdgcn_sched_group_barrier(0x300, 1, 0);                     // one LDS access (fragment read / V store)
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     // one VMEM read
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            [[maybe_unused]] const unsigned long long t2 = WXT_NOW();
+            chunk_finish(cb + 1, pnext, setv, PRot{}, tl);
+            chunk_load(cb + 1 + PP, setv, PRot{}, tl);
+            [[maybe_unused]] const unsigned long long t3 = WXT_NOW();
+            if (!(BSVD_WX_ABL & 8)) __syncthreads();
+#ifdef BSVD_WX_TL
+            { const unsigned long long t4 = WXT_NOW(); tl_acc[1] += t2 - t0; tl_acc[2] += t3 - t2; tl_acc[3] += t4 - t3; }
+#endif
+            continue;
+        }
+        [[maybe_unused]] const unsigned long long t0 = WXT_NOW();
+        if (!(BSVD_WX_ABL & 1) && phase != 0) xform();
         __builtin_amdgcn_sched_barrier(0);
-        mfma_phase();
+        [[maybe_unused]] const unsigned long long t1 = WXT_NOW();
+        if (!(BSVD_WX_ABL & 2)) mfma_phase();
         __builtin_amdgcn_sched_barrier(0);
-        if (phase == 0) transform_chunk(cn, pnext, cb + 1);
-        __syncthreads();
+        [[maybe_unused]] const unsigned long long t2 = WXT_NOW();
+        if (!(BSVD_WX_ABL & 1) && phase == 0) xform();
+        [[maybe_unused]] const unsigned long long t3 = WXT_NOW();
+        if (!(BSVD_WX_ABL & 8)) __syncthreads();
+#ifdef BSVD_WX_TL
+        { const unsigned long long t4 = WXT_NOW(); tl_acc[0] += t1 - t0; tl_acc[1] += t2 - t1; tl_acc[2] += t3 - t2; tl_acc[3] += t4 - t3; }
+#endif
+    }
     }
 
+    [[maybe_unused]] const unsigned long long tl_epi = WXT_NOW();
     // ---- epilogue: two rounds of publish -> finish
     const int Cq = p.Cout >> 2;
     auto coff16 = [](int c8) { return (c8 >> 4) * 16 + ((c8 >> 3) & 1) * 4; };
-    auto finish = [&](auto epi_c, auto act_c) {
+    auto finish = [&](auto epi_c, auto act_c) __attribute__((always_inline)) {
         constexpr int EPI = decltype(epi_c)::value, ACT = decltype(act_c)::value;
         const bool has_skip = EPI == BSVD_EPI_PS_ADD && p.extra != nullptr;
 #pragma unroll
@@ -326,7 +604,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), 1) void winox_kernel(
             __syncthreads();
             // finish: wave -> (block, column range)
             const int blk = wid % C::NBP, part = wid / C::NBP;
-            if (part >= C::NPART) continue;
+            if (part >= C::NPART || (BSVD_WX_ABL & 4)) continue;
             const int mtl = blk / (NH * NTW), ntg = blk % (NH * NTW);
             const int q = lane & 3;
             const int n8 = n0 + ntg * 32 + 8 * q;
@@ -419,6 +697,14 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), 1) void winox_kernel(
         else if (p.act == BSVD_ACT_RELU) finish(integral_constant<int, BSVD_EPI_PLAIN>{}, integral_constant<int, BSVD_ACT_RELU>{});
         else finish(integral_constant<int, BSVD_EPI_PLAIN>{}, integral_constant<int, BSVD_ACT_NONE>{});
     }
+#ifdef BSVD_WX_TL
+    if (lane == 0 && blockIdx.x < BSVD_WX_TL_SLOTS) {
+        const unsigned long long t_end = WXT_NOW();
+        unsigned long long *o = g_wx_tl[blockIdx.x][wid];
+        o[0] = tl_acc[0]; o[1] = tl_acc[1]; o[2] = tl_acc[2]; o[3] = tl_acc[3];
+        o[4] = tl_loop - tl_start; o[5] = t_end - tl_epi; o[6] = t_end - tl_start; o[7] = (unsigned long long)ncb;
+    }
+#endif
 }
 
 template <int M, int NH, int NTW>
@@ -445,6 +731,7 @@ static int launch_winox_cfg(const ConvParams &pin, hipStream_t stream, char *nam
 int launch_winox(const ConvParams &p, hipStream_t stream, char *name, int name_len)
 {
     switch (p.wino_m) {
+    case 22: return launch_winox_cfg<2, 1, 2>(p, stream, name, name_len);     // 4-wave workgroups, two per CU
     case 2: return launch_winox_cfg<2, 2, 2>(p, stream, name, name_len);
     case 4: return launch_winox_cfg<4, 2, 1>(p, stream, name, name_len);
     default: return launch_winox_cfg<6, 1, 2>(p, stream, name, name_len);
@@ -452,3 +739,10 @@ int launch_winox(const ConvParams &p, hipStream_t stream, char *name, int name_l
 }
 
 }  // namespace bsvd
+
+#ifdef BSVD_WX_TL
+extern "C" int bsvd_debug_wx_timeline(unsigned long long *dst, int n)     // measurement builds only; not in include/bsvd_hip.h
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(bsvd::g_wx_tl), sizeof(unsigned long long) * 12 * 8 * (size_t)n);
+}
+#endif

@@ -9,7 +9,7 @@ from bsvd_amd.engine import HipExecutor, PackedNet
 from bsvd_amd.netspec import ConvSpec
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
-forms = (sys.argv[2] if len(sys.argv) > 2 else "direct,wino2,wino4,wino6").split(",")
+forms = (sys.argv[2] if len(sys.argv) > 2 else "direct,wino2,wino2s,wino4,wino6").split(",")
 dev = torch.device("cuda", 0)
 rs = np.random.RandomState(0)
 LAYERS = [  # cin, cout, tsm, act, epi, H, W, T

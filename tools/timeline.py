@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-workgroup timeline of one conv launch from a -DBSVD_TIMELINE build of the library (BSVD_HIP_LIB=...):
 where a tile's time goes (prologue / K loop / epilogue) and how long a CU slot stays empty between two workgroups.
-usage: BSVD_HIP_LIB=bsvd_amd/_ab/lib_tl.so python tools/timeline.py [Cin=128] [Cout=128] [H=270] [W=480] [frames=10]"""
+usage: BSVD_HIP_LIB=build/ab/lib_tl.so python tools/timeline.py [Cin=128] [Cout=128] [H=270] [W=480] [frames=10]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
