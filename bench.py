@@ -88,6 +88,14 @@ class _Both:
         return sum(sp.macs(h, w) for sp in self.sps)
 
 
+def mfma_factor(kernel_name):
+    """MFMA flop issued per algorithmic flop by a kernel variant (name as bsvd_conv3x3_variant reports it)"""
+    import re
+    passes = 3.0 if "f16x3" in kernel_name else 1.0
+    m = re.search(r"F\((\d),3\)", kernel_name)                   # Winograd F(m,3) along x: 3 (m + 2) tap-GEMMs per m outputs instead of 9 per output
+    return passes * ((m_ := int(m.group(1))) + 2) * 3.0 / (9.0 * m_) if m else passes
+
+
 class LaunchTimer:
     """Wraps HipExecutor.conv with a HIP event pair per launch (same stream as the kernel).  Events come from a pool
     that is filled during the warmup steps and re-recorded in the timed region, and the kernel-variant names are cached
@@ -123,7 +131,12 @@ class LaunchTimer:
             T, _, Hh, Ww = x.shape
         else:
             T, Hh, Ww, _ = x.shape
-        self.records.append((sp, T, Hh, Ww, e0, e1, name))
+        # temporal-shift chunks the kernel leaves out of K (zero groups of a clip's first / last frame when no halo is supplied)
+        zs = 0
+        if getattr(sp, "tsm", False) and sp.fold % 16 == 0:
+            zs = (0 if (len(a) > 0 and a[0] is not None) or k.get("halo_prev") is not None else 1) + \
+                 (0 if (len(a) > 1 and a[1] is not None) or k.get("halo_next") is not None else 1)
+        self.records.append((sp, T, Hh, Ww, e0, e1, name, zs))
         return y
 
     def _fused(self, sp0, sp3, x, *a, **k):
@@ -138,7 +151,7 @@ class LaunchTimer:
         if name is None:
             name = self.names[key] = self.ex.last_variant
         T, _, Hh, Ww = x.shape
-        self.records.append((_Both(sp0, sp3), T, Hh, Ww, e0, e1, name))
+        self.records.append((_Both(sp0, sp3), T, Hh, Ww, e0, e1, name, 0))
         return y
 
     def reserve(self, steps):
@@ -159,12 +172,17 @@ class LaunchTimer:
         self.ex.record_variants = False
 
     def summary(self):
+        """per kernel variant: time, ALGORITHMIC flop (2 x MACs of the convolution) and the MFMA flop the kernel actually issues:
+        x passes (1 exact fp32, 3 split), x the tap-GEMMs of its arithmetic form over the direct form's 9 (Winograd F(m,3) along x:
+        3 (m + 2) / m), minus the all-zero temporal-shift chunks it leaves out of K (fold / Cin of one frame's K per missing neighbour)"""
         agg = {}
-        for sp, T, Hh, Ww, e0, e1, name in self.records:
+        for sp, T, Hh, Ww, e0, e1, name, zs in self.records:
             ms = e0.elapsed_time(e1)
-            d = agg.setdefault(name, {"ms": 0.0, "flop": 0.0, "launches": 0})
+            d = agg.setdefault(name, {"ms": 0.0, "flop": 0.0, "flop_issued": 0.0, "launches": 0})
+            flop = 2.0 * sp.macs(Hh, Ww) * T
             d["ms"] += ms
-            d["flop"] += 2.0 * sp.macs(Hh, Ww) * T
+            d["flop"] += flop
+            d["flop_issued"] += flop * mfma_factor(name) * (1.0 - zs * (sp.fold / sp.cin) / T if zs else 1.0)
             d["launches"] += 1
         return agg
 
@@ -257,19 +275,22 @@ def power_probe(step, seconds):
     th = threading.Thread(target=sample, daemon=True)
     th.start()
     t0 = time.perf_counter()
+    nsteps = 0
     with torch.no_grad():
         while time.perf_counter() - t0 < seconds:
             for _ in range(4):
                 step()
+            nsteps += 4
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
+    loop_s = time.perf_counter() - t0
     stop.set()
     th.join(timeout=15)
     rows = rows[1:] if len(rows) > 2 else rows                    # the first sample may predate the loop
     if not rows:
         return None
     return {"package_w": sum(r[0] for r in rows) / len(rows), "cap_w": float(cap.group(1)) if cap else None,
-            "sclk_mhz": sum(r[1] for r in rows) / len(rows), "samples": len(rows),
+            "sclk_mhz": sum(r[1] for r in rows) / len(rows), "samples": len(rows), "loop_steps": nsteps, "loop_seconds": loop_s,
             "source": "rocm-smi --showpower --showclocks every ~0.5 s while the same step loops for %.1f s after the timed region" % seconds}
 
 
@@ -452,6 +473,7 @@ def main():
                 for v in agg.values():         # scale to `steps` so that roofline_of's per-step figures stay per step
                     v["ms"] *= steps
                     v["flop"] *= steps
+                    v["flop_issued"] *= steps
                     v["launches"] *= steps
                 for e in model._stream_engs.values():
                     e.layerwise = False
@@ -492,15 +514,17 @@ def main():
                          "algorithmic FLOP, so MFMA-pipe utilisation = 3 x frac (mfma_pipe_frac).  The chip runs this at its "
                          "package power limit: the guide's own dense bf16 GEMM on random data sustains 1,247 TFLOP/s = 0.50 "
                          "of the 2.5 PFLOP/s peak (MI355X_MICROARCH.md, DVFS give-back)"),
-                "mfma_flop_per_algorithmic_flop": 1 if precision == "fp32" else 3,
-                "mfma_pipe_frac": ach * (1 if precision == "fp32" else 3) / peak,
+                "mfma_flop_per_algorithmic_flop": agg[dom]["flop_issued"] / agg[dom]["flop"],
+                "mfma_flop_issued_per_launch": agg[dom]["flop_issued"] / agg[dom]["launches"],
+                "mfma_pipe_frac": agg[dom]["flop_issued"] / (agg[dom]["ms"] * 1e-3) / 1e12 / peak,
                 "avg_launch_ms": agg[dom]["ms"] / agg[dom]["launches"], "launches": agg[dom]["launches"],
                 "all_conv_kernels": {k: {"ms_per_step": v["ms"] / steps, "tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12,
+                                         "mfma_tflops_issued": v["flop_issued"] / (v["ms"] * 1e-3) / 1e12,
                                          "launches_per_step": v["launches"] // steps} for k, v in agg.items()},
                 "conv_ms_per_step": sum(v["ms"] for v in agg.values()) / steps}
 
     # ---- the timed job (headline) ...
-    model, elapsed, agg, y = timed_run(args.precision, steps, warmup, args.prewarm_s, probe_s=0.0 if args.no_power_probe else 2.5)
+    model, elapsed, agg, y = timed_run(args.precision, steps, warmup, args.prewarm_s, probe_s=0.0 if args.no_power_probe else 5.0)
     stream_stats = getattr(model, "bench_stream_stats", None)
     model.release_stream_buffers()
     # ---- ... and, outside it, the other arithmetic mode on the same clip for reference + a live parity figure
@@ -515,7 +539,8 @@ def main():
         fps = total_frames / elapsed
         flop_per_frame = 2.0 * model.net.macs_per_frame(h, w)
         degraded = bool(halo_transport) and not halo_transport.startswith("rccl")
-        api = {"clip": "BSVD.forward (clip schedule: layer-major, 32 launches per clip)",
+        api = {"clip": "BSVD.clip_forward on the pre-concatenated [F,4,H,W] clip = BSVD.forward minus the 5-D reshape and the noise-map "
+                       "torch.cat (clip schedule: layer-major, every launch of the net inside the timed region)",
                "stream": "BSVD.streaming_forward (stream schedule on rings, HIP-graph replay, %s frames per pipeline step)"
                          % (stream_stats["chunk"] if stream_stats else "?"),
                "perframe": "BSVD.feedin_one_element per frame + 17 flush feeds (one HIP-graph replay per frame)"}[mode]
@@ -557,6 +582,11 @@ def main():
             pw["at_power_cap"] = bool(pw["cap_w"]) and pw["package_w"] >= 0.98 * pw["cap_w"]
             pw["mfma_pipe_frac_at_sampled_clock"] = out["roofline"]["mfma_pipe_frac"] / scale if scale > 0 else None
             out["power"] = pw
+            # the timed region is a short burst (the reference's protocol: profile.py takes the best of 10 short runs); a live stream
+            # gets what the chip sustains at its package power cap -- the same step looped for >= 5 s right after the timed region
+            out["sustained"] = {"value": frames * pw["loop_steps"] / pw["loop_seconds"], "unit": "frames/s", "seconds": pw["loop_seconds"],
+                                "sclk_mhz": pw["sclk_mhz"], "package_w": pw["package_w"],
+                                "note": "untimed loop of the same step after the timed region (N = 1); `value` above is the K-step burst"}
         if stream_stats:
             out["stream_engine"] = stream_stats
         if world > 1:

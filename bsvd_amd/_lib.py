@@ -52,6 +52,7 @@ class BsvdConvArgs(ctypes.Structure):
         ("head_bias", ctypes.c_void_p),
         ("w_wino_packed", ctypes.c_void_p),
         ("wino_m", ctypes.c_int32),
+        ("fat_min_wgs", ctypes.c_int32),
     ]
 
 
@@ -71,6 +72,9 @@ def load():
         raise BsvdLibraryError(
             "libbsvd_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
             "bsvd_amd/csrc/build.sh -- bsvd_amd has no CPU fallback." % LIB_PATH)
+    if os.environ.get("BSVD_HIP_LIB"):
+        import sys
+        print("bsvd_amd: BSVD_HIP_LIB override -- loading %s instead of the in-tree libbsvd_hip.so" % LIB_PATH, file=sys.stderr)
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
     lib.bsvd_abi_version.restype = ctypes.c_int

@@ -38,7 +38,7 @@ for _hook in ("register_module_parameter_registration_hook", "register_module_bu
 
 # Arithmetic form of the wide stride-1 layers in the split mode (engine.wino_eligible): 'direct' (3-pass implicit GEMM),
 # 'wino2' / 'wino4' (1-D Winograd F(2,3) / F(4,3) along x, conv3x3_wino.hip).  wide_conv='auto' takes BSVD_WIDE_CONV or this.
-WIDE_CONV_DEFAULT = "direct"
+WIDE_CONV_DEFAULT = "wino2"
 F16X3_WEIGHT_LIMIT = 6.0e4      # |folded weight| beyond this cannot be carried as an fp16 pair (fp16 max 65504)
 
 

@@ -322,6 +322,7 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
     p.halo_next = a->fold > 0 ? (const float *)a->halo_next : nullptr;
     p.w = (const float *)(a->w_wino_packed ? a->w_wino_packed : a->w_packed);
     p.wino_m = a->w_wino_packed ? a->wino_m : 0;
+    p.fat_min_wgs = a->fat_min_wgs > 0 ? a->fat_min_wgs : 0;
     p.bias = (const float *)a->bias_packed;
     p.extra = (const float *)a->extra;
     p.y = (float *)a->y;

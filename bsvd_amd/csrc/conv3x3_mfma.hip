@@ -1417,7 +1417,7 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
         // The fat tiles run one workgroup per CU, so they need a grid of several rounds of 256; small launches
         // (streaming mode: one frame per launch) keep the 64x64 tiles at 3 workgroups per CU.
         const int64_t fat_wide = (int64_t)p.frames * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16) * ((p.Cout + 127) / 128);
-        static const int fat_min = [] { const char *e = getenv("BSVD_FAT_MIN_WGS"); return e ? atoi(e) : BSVD_TUNE_FAT_MIN_WGS; }();   // tuning override
+        const int fat_min = p.fat_min_wgs > 0 ? p.fat_min_wgs : BSVD_TUNE_FAT_MIN_WGS;      // BsvdConvArgs.fat_min_wgs (0 = the measured default); no hidden state
 #ifndef BSVD_TUNE_THIN_ALT
 #define BSVD_TUNE_THIN_ALT 0       // 1: small grids of the wide layers (single-frame launches) on <4,1,2,2,1> (256 px x 64 ch workgroups, two channel tiles)
 #endif

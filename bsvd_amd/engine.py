@@ -38,12 +38,15 @@ def head_fusable(inc0, inc3, precision):
 WIDE_CONV = ("direct", "wino2", "wino4", "wino6", "wino2b", "wino4b", "wino2s")
 
 
-def wino_eligible(sp, precision):
+WINO_MIN_CIN = 128     # narrowest layer the Winograd form takes (engine.PackedNet(wino_min_cin=...))
+
+
+def wino_eligible(sp, precision, min_cin=WINO_MIN_CIN):
     """Layers the 1-D Winograd kernel (conv3x3_wino.hip) can take: the wide stride-1 layers of the split-fp16 mode --
     the temporal-fusion convs (bsvd_arch.py:21-50) and the UpBlock convs (:257-267) at >= 128 input channels.  The choice
     depends on the LAYER only (never on the clip length or frame size), so that every schedule -- clip, stream, sharded,
     MIMO -- runs the same arithmetic per layer and stays bit-identical to the others."""
-    return (precision == "f16x3" and sp.stride == 1 and sp.cin_pad >= 128 and sp.cout_pad % 32 == 0
+    return (precision == "f16x3" and sp.stride == 1 and sp.cin_pad >= max(128, min_cin) and sp.cout_pad % 32 == 0
             and sp.epilogue in (EPI_PLAIN, EPI_PS_ADD) and (not sp.tsm or sp.fold % 16 == 0))
 
 
@@ -51,7 +54,7 @@ class PackedNet:
     """Device-resident pre-packed weights of every layer (one-time transform of the state_dict,
     cf. BSVD.load, bsvd_arch.py:462-474): {spec.key: (w_packed, bias_packed)}."""
 
-    def __init__(self, net, state, device, precision="fp32", wide_conv="direct"):
+    def __init__(self, net, state, device, precision="fp32", wide_conv="direct", wino_min_cin=None):
         lib = require_hip()
         if wide_conv not in WIDE_CONV:
             raise ValueError("wide_conv must be one of %s" % (WIDE_CONV,))
@@ -61,6 +64,7 @@ class PackedNet:
         # F(m,3) form; the ABI's wino_m + 10 selects the all-positions-per-wave kernel (conv3x3_wino.hip, measurement variant)
         self.wino_m = {"direct": 0, "wino2": 2, "wino4": 4, "wino6": 6, "wino2b": 2, "wino4b": 4, "wino2s": 2}[wide_conv]
         self.wino_abi = self.wino_m + (10 if wide_conv.endswith("b") else 20 if wide_conv.endswith("s") else 0)
+        self.wino_min_cin = int(os.environ.get("BSVD_WINO_MIN_CIN", WINO_MIN_CIN)) if wino_min_cin is None else int(wino_min_cin)
         self.wino = {}               # {spec.key: transformed pack} of the layers that run on the Winograd kernel
         self.tensors = {}
         self.order = {sp.key: i for i, sp in enumerate(net.layers)}      # position in the layer-major walk (tile_order parity)
@@ -78,7 +82,7 @@ class PackedNet:
                 if tuple(w.shape) != (sp.cout, sp.cin, 3, 3):
                     raise ValueError("%s.weight has shape %s, expected %s" % (sp.key, tuple(w.shape), (sp.cout, sp.cin, 3, 3)))
                 bp = torch.empty(sp.cout_pad, dtype=torch.float32, device=device)
-                if self.wino_m and wino_eligible(sp, precision):
+                if self.wino_m and wino_eligible(sp, precision, self.wino_min_cin):
                     n = lib.bsvd_packed_wino_weight_elems(sp.cin_pad, sp.cout_pad, self.wino_m)
                     wq = torch.empty(n, dtype=torch.float32, device=device)
                     rc = lib.bsvd_pack_weights_wino(w.data_ptr(), b.data_ptr() if b is not None else None, sp.cin, sp.cout,
@@ -128,6 +132,9 @@ class HipExecutor:
         self.split = packed.precision == "f16x3"      # NHWC activations are split16 (hi|lo fp16 pairs per chunk)
         self.dtype = _lib.BSVD_F16X3 if self.split else _lib.BSVD_F32
         self.launches = 0
+        # tuning override of the direct form's fat-tile threshold (BsvdConvArgs.fat_min_wgs; 0 = library default).  Read HERE, on the
+        # host side of the ABI, once per executor -- the library itself reads no environment
+        self.fat_min_wgs = int(os.environ.get("BSVD_FAT_MIN_WGS", "0") or 0)
         self.record_variants = False     # profiling aid: ask the library which kernel instantiation each conv uses
         self.last_variant = None
 
@@ -311,4 +318,5 @@ class HipExecutor:
         a.act, a.epilogue, a.dtype = _lib.ACT[sp.act], sp.epilogue, self.dtype
         # consecutive layers walk their tiles in opposite directions: each starts where its producer finished (Infinity Cache)
         a.tile_order = self.packed.order.get(sp.key, 0) & 1
+        a.fat_min_wgs = self.fat_min_wgs
         return a, y

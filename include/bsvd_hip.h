@@ -125,6 +125,10 @@ typedef struct BsvdConvArgs {
      * Cout % 32 == 0, no planar / fused-entry / RESID options; anything else returns -19 with the reason. */
     const void *w_wino_packed;
     int32_t wino_m;
+    /* Tuning (ABI v9; 0 = the library's measured default, 800): the smallest grid, in 256-px x 128-channel workgroups, for which a
+     * wide direct-form BSVD_F16X3 layer takes the 128-accumulator tile instead of the 64-accumulator one.  Both tiles compute the
+     * same bits; the field replaces an environment variable the library used to read once per process. */
+    int32_t fat_min_wgs;
 } BsvdConvArgs;
 
 int bsvd_abi_version(void);

@@ -1,4 +1,4 @@
-"""Run in a fresh interpreter with BSVD_FAT_MIN_WGS=1 (the library reads it once per process): every split-mode layer with more than 64
+"""Run in a fresh interpreter with BSVD_FAT_MIN_WGS=1 (the Python executor reads it once and passes it as BsvdConvArgs.fat_min_wgs): every split-mode layer with more than 64
 output channels then takes the 128-accumulator tile whatever its grid, so small random geometries reach its special paths -- waves
 below the image for every H mod 16 in 1..8, zero-chunk skipping for T = 1 (both temporal neighbours missing), 2 and 3, every halo form,
 the PixelShuffle epilogue, masked output columns.  Prints one line per case and 'FUZZ OK n'."""

@@ -9,6 +9,9 @@
 //   case 4  3-layer chain in split-fp16 mode: planar 4-channel input -> head 4->64 -> conv 64->64 (BSVD_F16X3) -> tail
 //           64->3 with residual + clamp, planar output  (InputCvBlock / OutputCvBlock + none_minus :408-414)
 //
+//   case 8  the same temporal-fusion conv in split-fp16 mode in its Winograd F(2,3) form (ABI v9: bsvd_pack_weights_wino +
+//           BsvdConvArgs.w_wino_packed), the host doing the split16 encode / decode itself
+//
 // Built by __graft_entry__.build() (tests/native/Makefile); run by tests/test_gpu_native.py on the MI355X.
 #include <hip/hip_runtime_api.h>
 #include <math.h>
@@ -306,11 +309,83 @@ static void case_stream_ring_graphs() {
     HIP_OK(hipStreamDestroy(cap)); HIP_OK(hipStreamDestroy(run));
 }
 
+// ---- split16 on the host (what a non-Python consumer of BSVD_F16X3 tensors writes): fp32 <-> IEEE half, round to nearest even
+static uint16_t f2h(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u; x &= 0x7fffffffu;
+    if (x >= 0x47800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));      // overflow / inf / nan
+    if (x < 0x38800000u) {                                                                     // subnormal half or zero
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int e = (int)(x >> 23), sh = 126 - e;                                            // 14 .. 24
+        uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const uint32_t r = m >> sh, rem = m & ((1u << sh) - 1), half = 1u << (sh - 1);
+        return (uint16_t)(sign | (r + ((rem > half || (rem == half && (r & 1))) ? 1 : 0)));
+    }
+    const uint32_t r = x + 0xc8000fffu + ((x >> 13) & 1);                                      // rebias + round to nearest even
+    return (uint16_t)(sign | (r >> 13));
+}
+static float h2f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31, m = h & 1023u;
+    uint32_t x;
+    if (e == 0) { if (!m) x = sign; else { float v = (float)m * 5.9604644775390625e-8f; memcpy(&x, &v, 4); x |= sign; } }
+    else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f; memcpy(&f, &x, 4); return f;
+}
+// NHWC fp32 [..][C] (C % 16 == 0) -> split16: per 16-channel chunk [hi x16 | lo x16] halves in the same 64 bytes
+static std::vector<float> to_split16(const std::vector<float> &v) {
+    std::vector<float> o(v.size());
+    uint16_t *q = reinterpret_cast<uint16_t *>(o.data());
+    for (size_t c = 0; c < v.size(); c += 16)
+        for (int j = 0; j < 16; ++j) { const uint16_t hi = f2h(v[c + j]); q[2 * c + j] = hi; q[2 * c + 16 + j] = f2h(v[c + j] - h2f(hi)); }
+    return o;
+}
+static std::vector<float> from_split16(const std::vector<float> &s) {
+    std::vector<float> o(s.size());
+    const uint16_t *q = reinterpret_cast<const uint16_t *>(s.data());
+    for (size_t c = 0; c < s.size(); c += 16)
+        for (int j = 0; j < 16; ++j) o[c + j] = h2f(q[2 * c + j]) + h2f(q[2 * c + 16 + j]);
+    return o;
+}
+
+static void case_winograd() {
+    const int T = 3, C = 128, H = 21, W = 38, fold = C / 8;
+    auto x = randv((size_t)T * C * H * W, 1.f), w = randv((size_t)C * C * 9, 0.04f), b = randv(C, 0.1f);
+    auto prevf = randv((size_t)C * H * W, 1.f);                                              // left neighbour's frame; no right neighbour (zeros)
+    // the oracle sees the values the split16 tensors encode
+    auto xs = to_split16(to_nhwc(x, T, C, H, W, C)), ps = to_split16(to_nhwc(prevf, 1, C, H, W, C));
+    x = to_nchw(from_split16(xs), T, C, H, W, C); prevf = to_nchw(from_split16(ps), 1, C, H, W, C);
+    float *dx = dev(xs), *dp = dev(ps), *dy = dev_zeros((size_t)T * H * W * C);
+    float *dw = dev(w), *db = dev(b);
+    float *wq = dev_zeros((size_t)bsvd_packed_wino_weight_elems(C, C, 2)), *bq = dev_zeros(C);
+    ABI_OK(bsvd_pack_weights_wino(dw, db, C, C, C, C, 0, 2, wq, bq, nullptr));
+    BsvdConvArgs a; memset(&a, 0, sizeof(a));
+    a.x = dx; a.x_frame_stride = (int64_t)H * W * C; a.fold = fold;
+    a.halo_prev = dp; a.halo_prev_pstride = C; a.halo_prev_coff = fold;
+    a.w_wino_packed = wq; a.wino_m = 2; a.bias_packed = bq; a.y = dy; a.y_frame_stride = (int64_t)H * W * C;
+    a.frames = T; a.H = H; a.W = W; a.Cin = C; a.Cout = C; a.stride = 1; a.act = BSVD_ACT_RELU6; a.epilogue = BSVD_EPI_PLAIN; a.dtype = BSVD_F16X3;
+    char name[96]; ABI_OK(bsvd_conv3x3_variant(&a, name, sizeof(name)));
+    if (!strstr(name, "F(2,3)")) { printf("variant %s\n", name); ++failures; }
+    ABI_OK(bsvd_conv3x3(&a, nullptr)); HIP_OK(hipDeviceSynchronize());
+    auto got = to_nchw(from_split16(host(dy, (size_t)T * H * W * C)), T, C, H, W, C);
+    std::vector<float> want((size_t)T * C * H * W);
+    const size_t fr = (size_t)C * H * W, pl = (size_t)H * W;
+    std::vector<float> zeros(fr, 0.f);
+    for (int t = 0; t < T; ++t) {
+        const float *pv = (t == 0 ? prevf.data() : x.data() + (t - 1) * fr) + fold * pl;
+        const float *nx = (t == T - 1 ? zeros.data() : x.data() + (t + 1) * fr);
+        if (oracle_conv3x3(x.data() + t * fr, pv, nx, fold, w.data(), b.data(), C, C, H, W, 1, 2, 0, nullptr, want.data() + t * fr)) exit(4);
+    }
+    report("temporal-fusion conv 128->128 as Winograd F(2,3), split16 tensors, left halo only", maxabs(got, want), 2e-4);
+    a.stride = 2;
+    if (bsvd_conv3x3(&a, nullptr) != -19 || !strstr(bsvd_last_error(), "stride")) { printf("w_wino_packed + stride 2 not refused\n"); ++failures; }
+}
+
 int main() {
     if (bsvd_abi_version() != BSVD_ABI_VERSION || bsvd_conv_args_size() != (int)sizeof(BsvdConvArgs)) { printf("ABI mismatch\n"); return 1; }
     int n = 0; HIP_OK(hipGetDeviceCount(&n)); if (n < 1) { printf("no HIP device\n"); return 1; }
     HIP_OK(hipSetDevice(0));
-    case_tsm(); case_stride2(); case_pixel_shuffle(); case_split_chain(); case_fused_entry(); case_batch_and_graph(); case_stream_ring_graphs();
+    case_tsm(); case_stride2(); case_pixel_shuffle(); case_split_chain(); case_fused_entry(); case_batch_and_graph(); case_stream_ring_graphs(); case_winograd();
     printf(failures ? "abi_parity: %d FAILED\n" : "abi_parity: all cases ok\n", failures);
     return failures ? 1 : 0;
 }

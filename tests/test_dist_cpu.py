@@ -146,3 +146,86 @@ def test_device_buffer_branch_of_halo_exchange_with_a_stub_backend(monkeypatch):
         outs.append(ex.conv(sp, shards[r], halo_prev=hp, halo_next=hn))
     assert torch.equal(torch.cat(outs), whole)
     assert hx[0].bytes_sent == 8 * 12 * sp.fold * 4 and hx[0].exchanges == 1
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_edge_and_interior_ranks_pair_up_in_posting_order_on_a_stub_fabric(monkeypatch, world):
+    """What only N > 2 has: the outermost ranks post 2 point-to-point ops per temporal-fusion layer, interior ranks 4 (right
+    neighbour first, then left), all inside one batch_isend_irecv.  A stub fabric with NCCL's matching rule -- between a pair of
+    ranks, the k-th send of one meets the k-th receive of the other, in posting order -- carries the device-buffer branch of
+    HaloExchanger (host_staging False) for world 3 and 8, two consecutive layers (a second exchange must not pick up the first
+    one's slices): every rank's output equals its window of the unsharded layer, op counts and bytes are what bench.py's per-rank
+    `halo` block reports (VERDICT r03 #2; the reference cannot shard at all: validation_seq_infer.py:24)."""
+    import collections
+    import bsvd_amd.dist as D
+    from oracle_exec import OracleExecutor
+    from bsvd_amd.netspec import make_netspec
+
+    mailbox = collections.defaultdict(collections.deque)        # (src, dst) -> tensors in send order
+    posted = collections.defaultdict(list)                      # rank -> [(kind, peer)] in posting order
+    current = {"rank": None}
+
+    class Op:
+        def __init__(self, op, tensor, peer, group=None):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    class Req:
+        def __init__(self, kind, me, op):
+            self.kind, self.me, self.op = kind, me, op
+
+        def wait(self):
+            if self.kind == "recv":
+                src = mailbox[(self.op.peer, self.me)].popleft()          # k-th receive from a peer <- that peer's k-th send to me
+                assert src.shape == self.op.tensor.shape
+                self.op.tensor.copy_(src)
+
+    def batch(ops):
+        reqs = []
+        for o in ops:
+            posted[current["rank"]].append((o.op, o.peer))
+            if o.op == "isend":
+                mailbox[(current["rank"], o.peer)].append(o.tensor)
+            reqs.append(Req("send" if o.op == "isend" else "recv", current["rank"], o))
+        return reqs
+
+    monkeypatch.setattr(D.dist, "get_backend", lambda group=None: "nccl")
+    monkeypatch.setattr(D.dist, "P2POp", Op)
+    monkeypatch.setattr(D.dist, "isend", "isend")
+    monkeypatch.setattr(D.dist, "irecv", "irecv")
+    monkeypatch.setattr(D.dist, "batch_isend_irecv", batch)
+
+    g = load_golden("g4_bsvd_small_T7")
+    st = state_for(g, bsvd_keys([32, 64, 128], 32, 4, 3, 32))
+    net = make_netspec([32, 64, 128], 32, 4, 3, "relu6", 32)
+    sp1, sp2 = net.temp1["d0c1"], net.temp1["d0c2"]
+    ex = OracleExecutor(st)
+    torch.manual_seed(5)
+    T = 2 * world + 1                                            # ragged: one rank owns 3 frames
+    v = torch.rand(T, 8, 12, sp1.cin_pad)
+    whole1 = ex.conv(sp1, v)
+    whole2 = ex.conv(sp2, whole1)
+    spans = [D.shard_range(T, world, r) for r in range(world)]
+    hx = [D.HaloExchanger(ex, r, world) for r in range(world)]
+    cur = [v[a:b].contiguous() for a, b in spans]
+    for sp, whole in ((sp1, whole1), (sp2, whole2)):
+        pend = []
+        for r in range(world):                                   # every rank posts before anybody waits (overlapped schedule)
+            current["rank"] = r
+            pend.append(hx[r].start(sp, cur[r]))
+        nxt = []
+        for r in reversed(range(world)):                         # waits in any order
+            hp, hn = pend[r].finish()
+            assert (hp is None) == (r == 0) and (hn is None) == (r == world - 1)
+            nxt.append((r, ex.conv(sp, cur[r], halo_prev=hp, halo_next=hn)))
+        cur = [y for _, y in sorted(nxt)]
+        assert torch.equal(torch.cat(cur), whole)
+        assert all(len(q) == 0 for q in mailbox.values()), "every sent slice was received exactly once"
+    for r in range(world):
+        ops = posted[r]
+        edge = r in (0, world - 1)
+        assert len(ops) == (2 if edge else 4) * 2                # two layers
+        per_layer = ops[:len(ops) // 2]
+        want = ([("isend", r + 1), ("irecv", r + 1)] if r + 1 < world else []) + ([("isend", r - 1), ("irecv", r - 1)] if r > 0 else [])
+        assert per_layer == want and ops[len(ops) // 2:] == want
+        assert hx[r].exchanges == 2
+        assert hx[r].bytes_sent == (1 if edge else 2) * 8 * 12 * 4 * (sp1.fold + sp2.fold)

@@ -125,7 +125,7 @@ def test_random_networks_with_the_wide_layers_forced_onto_the_128_accumulator_ti
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, BSVD_FAT_MIN_WGS="1", PYTHONDONTWRITEBYTECODE="1")
+    env = dict(os.environ, BSVD_FAT_MIN_WGS="1", BSVD_WIDE_CONV="direct", PYTHONDONTWRITEBYTECODE="1")      # the direct form of the wide layers
     r = subprocess.run([sys.executable, os.path.join(here, "fat_tile_fuzz_driver.py"), "6", "nets"], env=env, capture_output=True,
                        text=True, timeout=900)
     print(r.stdout[-3000:])
