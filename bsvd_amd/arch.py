@@ -28,13 +28,27 @@ from .schedule import StreamPipeline, bsvd_clip, planar_ok
 _REGISTRATION_EPOCH = [0]
 
 
-def _bump_epoch(*_args, **_kwargs):
-    _REGISTRATION_EPOCH[0] += 1
+def _bump_epoch(module, *_args, **_kwargs):
+    # only registrations inside an engine's own module tree count (every module of it is tagged at construction and a sub-module
+    # attached later inherits the tag): other models of the process building or mutating themselves leave the engines' caches alone
+    if module.__dict__.get("_bsvd_owned"):
+        _REGISTRATION_EPOCH[0] += 1
+        for a in _args:
+            if isinstance(a, nn.Module):
+                for sm in a.modules():
+                    sm.__dict__["_bsvd_owned"] = True
 
 
-for _hook in ("register_module_parameter_registration_hook", "register_module_buffer_registration_hook",
-              "register_module_module_registration_hook"):
-    getattr(torch.nn.modules.module, _hook)(_bump_epoch)
+_HOOK_HANDLES = [getattr(torch.nn.modules.module, _hook)(_bump_epoch)
+                 for _hook in ("register_module_parameter_registration_hook", "register_module_buffer_registration_hook",
+                               "register_module_module_registration_hook")]
+
+
+def remove_registration_hooks():
+    """Detaches the three process-global torch.nn registration hooks this module installs at import (an embedding application that
+    never swaps parameters of a live engine can drop them; call ``model.refresh_parameters()`` by hand after such a swap then)."""
+    while _HOOK_HANDLES:
+        _HOOK_HANDLES.pop().remove()
 
 # Arithmetic form of the wide stride-1 layers in the split mode (engine.wino_eligible): 'direct' (3-pass implicit GEMM),
 # 'wino2' / 'wino4' (1-D Winograd F(2,3) / F(4,3) along x, conv3x3_wino.hip).  wide_conv='auto' takes BSVD_WIDE_CONV or this.
@@ -128,6 +142,7 @@ class _HipNet(nn.Module):
                              "i.e. chns[1:] = (64|128k, 128k) like the c64 and c32 networks, and <= 4 input/output "
                              "channels; offending layers: %s" % (bad[:3],))
         self.precision = precision
+        self._precision_init = precision       # what __init__ resolved; a weight-range fallback of 'auto' to fp32 lasts one pack only
         self._packed = None
         self._packed_sig = None
         self._exec = None
@@ -181,6 +196,11 @@ class _HipNet(nn.Module):
                 % (list(n.chns), n.mid_ch, n.net_in_ch, n.out_ch, n.act, n.interm_ch, n.blind, self.norm, self.precision,
                    self.precision_requested, len(n.layers), n.shift_num, n.macs_per_frame(540, 960) / 1e9))
 
+    def _tag_owned(self):
+        """marks every module of this engine's tree for the registration hooks (see _bump_epoch)"""
+        for sm in self.modules():
+            sm.__dict__["_bsvd_owned"] = True
+
     def refresh_parameters(self):
         self.__dict__.pop("_sig_tensors", None)
 
@@ -199,8 +219,11 @@ class _HipNet(nn.Module):
                                "running statistics; call .eval() first (DenoisingModel.test and profile.py do: "
                                "denoising_model.py:180, profile.py:80).  Training is out of scope of this engine.")
         require_hip()
-        sig = (self._signature(), str(device), self.precision, self.wide_conv)
+        sig = (self._signature(), str(device), self._precision_init, self.wide_conv)
         if self._packed is None or self._packed_sig != sig:
+            # every re-pack starts from the precision the constructor resolved: 'auto' that fell back to exact fp32 because ONE
+            # checkpoint's folded weights left fp16's range takes the split mode again when an in-range checkpoint is loaded
+            self.precision = self._precision_init
             # the ring/graph engines of the stream schedule bake the packed-weight addresses into their launch plans: drop them
             # BEFORE the old pack is freed (a new executor may even reuse the old one's id())
             if getattr(self, "_stream_engs", None):
@@ -217,7 +240,6 @@ class _HipNet(nn.Module):
                         warnings.warn("bsvd_amd: max |weight| after the BatchNorm fold is %.3g, outside fp16's range: "
                                       "precision='auto' falls back to exact fp32 for this network" % wmax)
                         self.precision = "fp32"
-                        sig = (sig[0], sig[1], self.precision, self.wide_conv)
                     else:
                         raise ValueError("precision='f16x3': max |weight| after the BatchNorm fold is %.3g, outside fp16's "
                                          "range (use precision='fp32' or 'auto')" % wmax)
@@ -316,6 +338,7 @@ class BSVD(_HipNet):
         self._reset(self.temp2)
         self.shift_num = self.net.shift_num
         self.reset_params()
+        self._tag_owned()
         self._pipe = None
         if pretrain_ckpt is not None:
             self.load(pretrain_ckpt)
@@ -344,6 +367,7 @@ class BSVD(_HipNet):
             eng.release()
         self._stream_engs, self._stream_key = {}, None
         self.__dict__.pop("_ring_oom", None)          # memory may be there again: let the next stream try its rings afresh
+        self.__dict__.pop("_mode_cache", None)        # ... and 'auto' re-evaluate clip vs stream for the next clip
 
     @property
     def _stream_eng(self):
@@ -451,6 +475,13 @@ class BSVD(_HipNet):
             if not pout:
                 y = ex.to_nchw(y, self.net.out_ch, self.clamp)
             return y.to(getattr(self, "_last_dtype", torch.float32))
+
+    def overlap_available(self, frame_shape):
+        """True if ``feed_overlapped`` can run for frames shaped (C,H,W): the ring engine exists for this network / device state
+        (stream_rings, planar edge layers, the rings fit the free HBM).  Builds and caches the engine the first feed would build."""
+        dev = self._device()
+        with torch.no_grad(), torch.cuda.device(dev):
+            return self._stream_engine(self._executor(dev), tuple(frame_shape)) is not None
 
     def feed_overlapped(self, x, last=False):
         """Per-frame feed for hosts that pipeline anyway (``pipeline.LiveStream`` with depth >= 2): like ``feedin_one_element``,
@@ -680,6 +711,7 @@ class TSN(_HipNet):
             stages.append(blk)
         self.base_model = _Slots(nets_list=nn.ModuleList(stages))
         self.reset_params()
+        self._tag_owned()
 
     def _bsvd_state(self):
         return checkpoint.to_bsvd_state(self.state_dict())

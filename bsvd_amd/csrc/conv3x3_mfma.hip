@@ -749,7 +749,8 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 _Float16 h4[4], l4[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float v = (ok && c < p.head_cin) ? xin[c * plane + (int64_t)gy * p.W + gx] : 0.f;
+                    float v = (ok && c < p.head_cin) ? xin[c * plane + (int64_t)gy * p.W + gx] : 0.f;
+                    v = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);      // fp16 range guard like every split store: saturate, never an inf / NaN pair
                     h4[c] = (_Float16)v;
                     l4[c] = lo_keep((_Float16)(v - (float)h4[c]));
                 }
@@ -844,7 +845,8 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
             // its own loop: it stages its share of every chunk and meets the chunk barriers, but reads no fragments and issues
             // no MFMAs.  (Guarding the reads / MFMAs of the common loop with a wave-uniform branch instead cost every wave its
             // cross-tap schedule: 19.49 -> 19.83 ms per C1 clip.)
-            const bool wlive = (BSVD_TUNE_SKIP_DEAD && LITE) ? oy0 + 2 * C::MT * wm < p.Ho : true;
+            // (never with the fused entry: its live loop has the head_pair barriers the staging-only loop lacks)
+            const bool wlive = (BSVD_TUNE_SKIP_DEAD && LITE && !HEADF) ? oy0 + 2 * C::MT * wm < p.Ho : true;
             if (!wlive) {
                 for (int cb = 0; cb < ncb; ++cb) {
                     ChunkSrc cn = chunk_src(cb + 1 < ncb ? cb + 1 : cb);
@@ -1358,6 +1360,15 @@ static int launch_cfg(const ConvParams &pin, hipStream_t stream, char *name = nu
     return (int)hipGetLastError();
 }
 
+// the fused network entry exists for the quad-planar 64-channel tile only: a tuning build without that layout (BSVD_TUNE_QPL bit 2
+// off) must not instantiate it (static_assert in head_pair) -- it reports the missing kernel instead
+template <class C>
+static int launch_headf(const ConvParams &p, hipStream_t stream, char *name, int name_len)
+{
+    if constexpr (C::QPL) return launch_cfg<C, true, 1, false, true>(p, stream, name, name_len);
+    else { set_error("bsvd_conv3x3: this build (BSVD_TUNE_QPL without bit 2) has no fused-entry kernel"); return -18; }
+}
+
 static bool fast_ok(const ConvParams &p, bool honour_force_generic = true)
 {
     // FAST needs: 16-B aligned vector gather (vec_ok), single-source 16-channel chunks (fold % 16 == 0) and
@@ -1403,7 +1414,7 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
 #endif
         if (p.head_w) {                  // fused network entry (validated by the ABI layer): the 64-channel tile with the first conv inside
             if (stride != 1 || p.fold != 0 || p.Cout > 64 || (p.Cin & 31)) { set_error("bsvd_conv3x3: fused entry needs stride 1, fold 0, Cin %% 32 == 0, Cout <= 64"); return -18; }
-            return launch_cfg<ConvCfg<4, 1, 2, 2, 1, 3>, true, 1, false, true>(p, stream, name, name_len);
+            return launch_headf<ConvCfg<4, 1, 2, 2, 1, 3>>(p, stream, name, name_len);
         }
         if (p.y_planar_ch > 0) {         // network exit: 256 px x 32 ch tiles, planar fp32 epilogue
             if (stride != 1 || p.fold != 0 || p.Cout > 32) { set_error("bsvd_conv3x3: planar split output needs stride 1, fold 0, Cout <= 32"); return -16; }

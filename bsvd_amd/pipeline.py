@@ -143,6 +143,8 @@ class LiveStream:
             raise ValueError("depth must be >= 1")
         self.model, self.sigma, self.depth = model, sigma, depth
         self.overlap = (depth >= 2) if overlap_blocks is None else bool(overlap_blocks)
+        self._overlap_explicit = overlap_blocks is not None
+        self._overlap_checked = not self.overlap
         self.latency = model.shift_num + depth - 1 + (1 if self.overlap else 0)     # feeds between a frame going in and coming out
         self.device = model._device()
         if self.device.type != "cuda":
@@ -171,6 +173,19 @@ class LiveStream:
         return slot.pin_out.numpy().copy() if has_out else None
 
     def _step(self, frame_u8, last=False):
+        if not self._overlap_checked and frame_u8 is not None:
+            # the lagged two-branch schedule needs the ring engine (stream_rings, planar edge layers, rings that fit the free HBM).
+            # Decided ONCE, before the first frame touches the stream: a default (overlap_blocks=None) falls back to the plain
+            # per-frame feed -- one feed less latency, same frames --, an explicit overlap_blocks=True raises here, with the
+            # stream still untouched, instead of half-way through a step
+            self._overlap_checked = True
+            h, w = frame_u8.shape[:2]
+            if not self.model.overlap_available((self.model.net.net_in_ch, h, w)):
+                if self._overlap_explicit:
+                    raise RuntimeError("LiveStream(overlap_blocks=True) needs the ring engine (stream_rings=True, planar edge layers, "
+                                       "enough free HBM for the rings); use overlap_blocks=False")
+                self.overlap = False
+                self.latency -= 1
         slot = self.slots[self.count % len(self.slots)]
         self.count += 1
         with torch.cuda.device(self.device):

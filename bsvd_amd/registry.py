@@ -98,6 +98,8 @@ def install(replace=False, import_reference=True):
     ``ValFolderDataset``).  Free names are always taken; names the reference plug-in holds are swapped only with
     ``replace=True`` (the registry entry is exchanged, nothing asserts).  ``import_reference``: import the reference's
     plug-in packages first when they are importable, so their import-time registrations cannot collide afterwards
+    (import-order caveat: a reference plug-in imported AFTER ``install()`` took a free stock name trips BasicSR's duplicate
+    assertion at its own ``register()`` -- call ``uninstall()`` first, or let ``install`` do the import, which is the default)
     (``Experimental_root.data`` needs NVIDIA DALI and normally fails on ROCm -- then ``ValFolderDataset`` is simply free).
     Returns {kind: {name: 'engine' | 'reference'}}: who answers to each stock name now."""
     if import_reference and HAVE_BASICSR:
@@ -139,19 +141,31 @@ def engine_name(kind, name):
     return name
 
 
+def _lookup(kind, name):
+    """The class ``bsvd_amd.build_*`` instantiates for ``name``: whatever the registry holds under it -- and, when BasicSR is
+    importable, ``install()`` has not run and the stock name is therefore still FREE (the engine only registers
+    ``<name>_MI355X`` so as not to squat on the reference's names), the engine's own class for that stock name.  The same
+    ``bsvd_amd.build_network({'type': 'BSVD'})`` thus works stand-alone and plugged in; a name the REFERENCE holds is never
+    shadowed here (that takes ``install(replace=True)``)."""
+    reg = _REGS[kind]
+    if name not in reg._obj_map and name in _ENGINE[kind]:
+        return _ENGINE[kind][name]
+    return reg.get(name)
+
+
 def build_network(opt):
     """basicsr.archs.build_network (basicsr/archs/__init__.py:19-25): pops ``type`` and instantiates the registered class
     with the rest."""
     opt = dict(opt)
     net_type = opt.pop("type")
-    return ARCH_REGISTRY.get(net_type)(**opt)
+    return _lookup("arch", net_type)(**opt)
 
 
 def build_dataset(dataset_opt):
     """basicsr.data.build_dataset (basicsr/data/__init__.py:25)."""
-    return DATASET_REGISTRY.get(dataset_opt["type"])(dict(dataset_opt))
+    return _lookup("dataset", dataset_opt["type"])(dict(dataset_opt))
 
 
 def build_model(opt):
     """basicsr.models.build_model (basicsr/models/__init__.py:19-30)."""
-    return MODEL_REGISTRY.get(opt["model_type"])(dict(opt))
+    return _lookup("model", opt["model_type"])(dict(opt))

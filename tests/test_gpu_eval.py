@@ -241,3 +241,32 @@ def test_validation_through_the_test_pipeline_calls(tmp_path):
     assert abs(tot2["psnr"] - total["psnr"]) < 1e-4 and set(per_folder) == {"a", "b"}
     img = np.asarray(Image.open(tmp_path / "vis" / "syn" / "a" / "00000000_run3.png"))
     assert img.shape == (30, 50, 3)
+
+
+def test_live_stream_falls_back_when_the_ring_engine_is_unavailable():
+    """LiveStream's default (overlap_blocks=None -> on for depth >= 2) must not break a model whose ring engine cannot
+    be built (stream_rings=False here; a ring allocation that hits OOM takes the same path): it runs the plain per-frame feed with
+    one feed less latency and the same bytes; an EXPLICIT overlap_blocks=True raises before the stream is touched."""
+    import bsvd_amd
+    from bsvd_amd.frame_io import frames_to_input, output_to_frames
+    from bsvd_amd.pipeline import LiveStream
+    rs = np.random.RandomState(33)
+    dev = torch.device("cuda", 0)
+    st = seeded_state(bsvd_keys([64, 128, 256], 64, 4, 3, 64), 11)
+    m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, in_ch=4, out_ch=3, norm="none", act="relu6", interm_ch=64,
+                      pretrain_ckpt=None, precision="f16x3", stream_rings=False)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
+    m = m.to(dev)
+    sigma = 30 / 255.0
+    frames = rs.randint(0, 256, (19, 32, 48, 3)).astype(np.uint8)
+    want = output_to_frames(m.clip_forward(frames_to_input(torch.from_numpy(frames).to(dev), sigma))).cpu().numpy()
+    live = LiveStream(m, sigma=sigma, depth=2)
+    assert live.overlap and live.latency == m.shift_num + 2
+    got = [r for r in (live.feed(f) for f in frames) if r is not None]
+    assert not live.overlap and live.latency == m.shift_num + 1          # decided at the first frame
+    got += live.flush()
+    assert len(got) == 19 and np.array_equal(np.stack(got), want)
+    strict = LiveStream(m, sigma=sigma, depth=2, overlap_blocks=True)
+    with pytest.raises(RuntimeError, match="ring engine"):
+        strict.feed(frames[0])
+    assert strict.count == 0 and not strict.inflight                     # nothing half-advanced

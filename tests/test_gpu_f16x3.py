@@ -11,7 +11,7 @@ from seeded import seeded_state
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3          # north_star budget
-TIGHT = 2e-4        # what the 3-pass split is expected to deliver on O(10) outputs
+TIGHT = 1.5e-4      # what the 3-pass split is expected to deliver on O(10) outputs (measured: layers 3-9e-6, whole nets 2-7e-5)
 
 
 def _dev():

@@ -251,9 +251,54 @@ def test_headline_clip_c1_whole_clip_vs_cpu_oracle_both_precisions(capsys):
         report[precision] = err
         assert tuple(y.shape) == (10, 3, 540, 960)
         assert err < 1e-3, (precision, err)
-        assert err < (3e-4 if precision == "f16x3" else 1.5e-4), (precision, err)      # regression guard, well inside the budget
+        assert err < (1.7e-4 if precision == "f16x3" else 1.6e-4), (precision, err)    # regression guard at 2x the measured 8.5e-5 / 7.9e-5
         del m, y
     with capsys.disabled():
         print("\n[C1 whole-clip parity] [1,10,4,540,960] vs CPU oracle (%.1f s on %d threads, |out|max %.2f): "
               "max-abs f16x3 %.3e, exact fp32 %.3e (budget 1e-3)"
               % (t_cpu, torch.get_num_threads(), float(want.abs().max()), report["f16x3"], report["fp32"]))
+
+
+@pytest.mark.parametrize("config", ["c2", "c3"])
+def test_c2_c3_ten_frame_whole_clips_vs_cpu_oracle_both_precisions(config, capsys):
+    """BASELINE configs C2 (DAVIS-2017 480p geometry, 480x856, sigma 30) and C3 (Set8 geometry, 540x960, blind bsvd_c64: 3-channel
+    input, interm_ch 30, unbounded ReLU -- WNet semantics) as WHOLE 10-frame clips against the CPU oracle in both arithmetic modes,
+    printed into the driver's GPU-test log like the C1 test above (the 85-frame clips of the real datasets are
+    covered by the size-independent properties: temporal locality, stream == clip).  ~15 s of host time each."""
+    import os
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import bsvd_amd
+    from oracle import bsvd_oracle as O
+    torch.set_num_threads(bench.usable_cores())
+    blind = config == "c3"
+    h, w = (480, 856) if config == "c2" else (540, 960)
+    g = torch.Generator().manual_seed(20260929 + blind)
+    clean = torch.nn.functional.avg_pool2d(torch.rand((10, 3, h, w), generator=g), 5, 1, 2)[None]
+    lq = clean + torch.randn(clean.shape, generator=g) * (30.0 / 255.0)
+    nm = torch.full((1, 10, 1, h, w), 30.0 / 255.0)
+    st = seeded_state(bsvd_keys([64, 128, 256], 64, 4, 3, 30 if blind else 64, blind=blind), 12 + blind)
+    cfg = O.default_cfg(act="relu", interm_ch=30, blind=True) if blind else O.default_cfg()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        want = (O.bsvd_clip(lq, O.to_torch_state(st), cfg) if blind else O.bsvd_clip(lq, O.to_torch_state(st), cfg, noise_map=nm))[0]
+    t_cpu = time.perf_counter() - t0
+    x = (lq if blind else torch.cat([lq, nm], dim=2)).to(_dev())
+    report = {}
+    for precision in PRECISIONS:
+        m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, in_ch=4, out_ch=3, norm="none", act="relu" if blind else "relu6",
+                          interm_ch=30 if blind else 64, blind=blind, pretrain_ckpt=None, precision=precision)
+        m.load_state_dict({k: torch.as_tensor(v) for k, v in st.items()})
+        y = m.to(_dev())(x)[0]
+        torch.cuda.synchronize()
+        err = float((y.cpu() - want).abs().max())
+        report[precision] = err
+        assert tuple(y.shape) == (10, 3, h, w) and err < 1e-3, (config, precision, err)
+        # regression guard at 2x the measured worst (r04: c2 7.3e-5 / 5.7e-5, c3 blind 9.3e-5 / 8.6e-5 at |out| 20)
+        assert err < ((1.9e-4 if precision == "f16x3" else 1.8e-4) if blind else (1.5e-4 if precision == "f16x3" else 1.2e-4)), (config, precision, err)
+        del m, y
+    with capsys.disabled():
+        print("\n[%s whole-clip parity] [1,10,%d,%d,%d] vs CPU oracle (%.1f s on %d threads, |out|max %.2f): max-abs f16x3 %.3e, exact fp32 %.3e (budget 1e-3)"
+              % (config.upper(), 3 if blind else 4, h, w, t_cpu, torch.get_num_threads(), float(want.abs().max()), report["f16x3"], report["fp32"]))

@@ -16,6 +16,8 @@ from seeded import seeded_state, state_digest
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
+F16X3_TOL = 1.5e-4     # split-fp16 mode against the reference goldens / the CPU oracle: >= 2x the measured worst (r04: 2-6e-5 on the
+                       # goldens, 8.5e-5 on the whole C1 clip; budget 1e-3)
 
 
 def _dev():
@@ -209,7 +211,7 @@ def test_golden_default_ctor_odd_channels(precision):
     y = m(x[:, :, :3], noise_map=x[:, :, 3:4])
     err = maxabs(y.cpu().numpy(), g["out"])
     print("reference-default ctor, %s: max-abs vs golden %.2e" % (precision, err))
-    assert err < (TOL if precision == "fp32" else 3e-4)
+    assert err < (TOL if precision == "fp32" else F16X3_TOL)      # measured 2.0e-5
     m.engine_mode = "stream"
     assert torch.equal(m(x[:, :, :3], noise_map=x[:, :, 3:4]), y)
 
@@ -270,7 +272,7 @@ def test_golden_blind_from_tsn_checkpoint(tmp_path, precision):
     y = m(torch.from_numpy(g["x"]).to(_dev()))
     err = maxabs(y.cpu().numpy(), g["out"])
     print("blind c64 %s max-abs vs the reference golden: %.2e" % (precision, err))
-    assert err < (TOL if precision == "fp32" else 3e-4)
+    assert err < (TOL if precision == "fp32" else F16X3_TOL)      # measured 3.9e-5
     m.engine_mode = "stream"
     assert torch.equal(m(torch.from_numpy(g["x"]).to(_dev())), y)
 
@@ -416,7 +418,7 @@ def test_tsn_blind_whole_clip_on_gpu(precision):
     gq.set_batch_index(0)
     y = m(torch.from_numpy(g["x"]).to(_dev()))
     gq._clean()
-    assert maxabs(y.cpu().numpy(), g["out"]) < (TOL if precision == "fp32" else 3e-4)
+    assert maxabs(y.cpu().numpy(), g["out"]) < (TOL if precision == "fp32" else F16X3_TOL)
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 4, 4, 4), (1, 2, 4, 8, 4), (2, 3, 4, 12, 20), (1, 1, 4, 4, 132)])
@@ -429,7 +431,7 @@ def test_tiny_and_ragged_clips_vs_oracle(shape):
     x = torch.from_numpy(seeded_clip(shape, 52))
     want = O.bsvd_clip(x, O.to_torch_state(st))
     import bsvd_amd
-    for precision, tol in (("fp32", TOL), ("f16x3", 2e-4)):
+    for precision, tol in (("fp32", TOL), ("f16x3", F16X3_TOL)):
         for mode in ("clip", "stream"):
             m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, norm="none", act="relu6", interm_ch=64, pretrain_ckpt=None,
                               engine_mode=mode, precision=precision)
