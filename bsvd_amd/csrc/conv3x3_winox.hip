@@ -14,6 +14,7 @@
 // reuse), two or three waves per SIMD.  The positions meet in the epilogue, through LDS.
 //
 // Pixel tile: 8 groups x 16 rows (8 M px wide); MFMA tile mt = rows 4 mt .. 4 mt + 3, lane li <-> (row li >> 3, group li & 7).
+// (MT = 2: 8 rows -- the same per-output instruction sequence on half the tile, taken by grids too small to fill the chip.)
 // K loop: 16-channel chunks; per chunk and wave 3 steps (ky) of 3 passes x 4 x NTW MFMAs.
 //   * group operand V[xi]: the chunk's transformed activations, double-buffered in LDS as planes [xi][quarter: hi c0-7,
 //     hi c8-15, lo c0-7, lo c8-15][patch row 0..17][group 0..7] x 16 B.  A fragment's 32 lanes read 32 consecutive slots
@@ -35,6 +36,7 @@
 #include "wino_forms.h"
 
 #define BSVD_WX_OOB 0x7fffffffu
+#define BSVD_CUS 256       // MI355X: 256 CUs, one 8-wave workgroup of this kernel each (the tile choice of small grids, launch_winox)
 #ifndef BSVD_WX_ILV
 #define BSVD_WX_ILV 0      // 1: the transform of the next chunk is interleaved INTO each wave's own MFMA stream (sched_group_barrier pipeline) instead of
                            //    running as a separate phase: a wave that streams MFMAs leaves the other wave of its SIMD about one VALU issue per MFMA
@@ -76,12 +78,13 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-template <int M_, int NH_, int NTW_>
+template <int M_, int NH_, int NTW_, int MT_ = 4>
 struct XCfg {
     static constexpr int M = M_, A = M + 2, NH = NH_, NTW = NTW_;
     static constexpr int NW = A * NH, NTHREADS = NW * 64;
-    static constexpr int MT = 4;                  // MFMA tiles of the pixel tile: 8 groups x 4 rows each
-    static constexpr int TR = 16, TWPX = 8 * M;   // pixel tile: 16 rows x 8 M columns
+    static constexpr int MT = MT_;                // MFMA tiles of the pixel tile: 8 groups x 4 rows each.  MT = 2: the half-height tile small grids
+                                                  // take (launch_winox) -- same arithmetic per output, twice the workgroups
+    static constexpr int TR = 4 * MT, TWPX = 8 * M;   // pixel tile: 16 (8) rows x 8 M columns
     static constexpr int PR = TR + 2;             // patch rows
     static constexpr int NSLOT = PR * 8;
     static constexpr int PLANE = NSLOT * 16;      // bytes of one (xi, quarter) plane
@@ -94,6 +97,7 @@ struct XCfg {
     static constexpr int LDS_BYTES = 2 * V_BUF > XCH_BYTES ? 2 * V_BUF : XCH_BYTES;
     static constexpr int NPART = NW / NBP >= 2 ? 2 : 1;          // finishers per block (column ranges)
     static_assert(LDS_BYTES <= 160 * 1024 && NW * 64 <= 1024 && NW % 4 == 0 && NW >= NBP, "");
+    static_assert(MT == 4 || (MT == 2 && NTHREADS != 768), "item map of the half-height tile: 512- and 256-thread workgroups");
     static constexpr int WGS = LDS_BYTES <= 80 * 1024 && NW == 4 ? 2 : 1;      // workgroups per CU
     static constexpr int NPH = NW / 4 > 1 ? NW / 4 : 2;   // waves per SIMD = phases of the chunk schedule (4-wave workgroups: waves 0-1 / 2-3)
 };
@@ -166,10 +170,10 @@ __device__ __forceinline__ XChunkSrc x_chunk_src(const XSources s, int cbl)     
 
 }  // namespace
 
-template <int M, int NH, int NTW>
-__global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), (XCfg<M, NH, NTW>::NW / 4 * XCfg<M, NH, NTW>::WGS)) void winox_kernel(const ConvParams p)
+template <int M, int NH, int NTW, int MT>
+__global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW, MT>::NW / 4 * XCfg<M, NH, NTW, MT>::WGS)) void winox_kernel(const ConvParams p)
 {
-    using C = XCfg<M, NH, NTW>;
+    using C = XCfg<M, NH, NTW, MT>;
     using F = WinoForm<M>;
     constexpr int A = C::A;
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
@@ -334,10 +338,12 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), (XCfg<M, NH, NTW>::NW
     // BAL (the interleaved schedule): no rotating waves -- the left-over items are dealt 16 lanes to every wave as a third, partial item
     // (a quarter of its lanes active: more instructions per wave, but every wave the same, and all of it in the MFMAs' shadow; a rotating
     // wave's extra item held the chunk barrier up for ~2000 cycles of 7900)
+    // The half-height tile (10 patch rows): one full item per lane instead of two, the same left-over blocks (rows 8, 9).
     constexpr bool BAL = BSVD_WX_ILV == 2 && C::NTHREADS != 768;
-    constexpr int NMAIN = C::NTHREADS == 768 ? 1 : BAL ? 3 : 2;
+    constexpr int NFULL = C::MT == 4 ? 2 : 1;                                                 // whole-workgroup item sweeps per chunk
+    constexpr int NMAIN = C::NTHREADS == 768 ? 1 : BAL ? NFULL + 1 : NFULL;
     constexpr int NROT = (C::NTHREADS == 768 || BAL) ? 0 : C::NTHREADS == 512 ? 2 : 1;      // 64-item blocks left over per chunk
-    constexpr int ROT0 = 2 * C::NTHREADS;                                                     // first left-over item
+    constexpr int ROT0 = NFULL * C::NTHREADS;                                                 // first left-over item
     static_assert(C::NTHREADS == 768 || C::NTHREADS == 512 || C::NTHREADS == 256, "item map");
     auto lane_id = [&]() __attribute__((always_inline)) {      // opaque per use: the item geometry is re-derived per chunk -- hoisted out of the K loop it pins ~30 registers
         int tl = lane;
@@ -345,10 +351,10 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), (XCfg<M, NH, NTW>::NW
         return tl;
     };
     auto main_E = [&](int k, int tl) __attribute__((always_inline)) {
-        return C::NTHREADS == 768 ? wid * 48 + tl : k < 2 ? k * C::NTHREADS + wid * 64 + tl : ROT0 + wid * (64 * (C::NTHREADS == 512 ? 2 : 1) / C::NW) + tl;
+        return C::NTHREADS == 768 ? wid * 48 + tl : k < NFULL ? k * C::NTHREADS + wid * 64 + tl : ROT0 + wid * (64 * (C::NTHREADS == 512 ? 2 : 1) / C::NW) + tl;
     };
     auto main_active = [&](int k, int tl) __attribute__((always_inline)) {
-        return C::NTHREADS == 768 ? tl < 48 : k < 2 ? true : tl < 64 * (C::NTHREADS == 512 ? 2 : 1) / C::NW;
+        return C::NTHREADS == 768 ? tl < 48 : k < NFULL ? true : tl < 64 * (C::NTHREADS == 512 ? 2 : 1) / C::NW;
     };
     auto rot_slot = [&](int cc) __attribute__((always_inline)) {                // 0 / 1: this wave takes left-over block 0 / 1 of chunk cc, -1: none
         if constexpr (NROT == 0) return -1;
@@ -422,12 +428,12 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), (XCfg<M, NH, NTW>::NW
             f32x4 afr[2][2];          // fragments one (ky, mt) step ahead, see the interleaved schedule
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) afr[0][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE);
-            static_for<0, 12>([&](auto k_) __attribute__((always_inline)) {
-                constexpr int S_ = decltype(k_)::value, KY = S_ / 4, mt = S_ % 4;
+            static_for<0, 3 * C::MT>([&](auto k_) __attribute__((always_inline)) {
+                constexpr int S_ = decltype(k_)::value, KY = S_ / C::MT, mt = S_ % C::MT;
                 const f32x4 (&b)[NTW][2] = bring[KY];
                 {
-                    if constexpr (S_ < 11) {
-                        constexpr int KY1 = (S_ + 1) / 4, mt1 = (S_ + 1) % 4;
+                    if constexpr (S_ < 3 * C::MT - 1) {
+                        constexpr int KY1 = (S_ + 1) / C::MT, mt1 = (S_ + 1) % C::MT;
 #pragma unroll
                         for (int pt = 0; pt < 2; ++pt)
                             afr[(S_ + 1) & 1][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE + (4 * mt1 + KY1) * 128);
@@ -475,7 +481,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), (XCfg<M, NH, NTW>::NW
             using PRot = std::integral_constant<int, 2>;
             constexpr int NU = NDW * NMAIN;                  // (item, channel pair) units: unit = k * NDW + cp
             constexpr int NST = 4 * NU;
-            constexpr int SPS = (NST + 11) / 12;             // stages per slot
+            constexpr int SPS = (NST + 3 * C::MT - 1) / (3 * C::MT);             // stages per slot
             static_assert(PP == 1, "the interleaved schedule requests an item one iteration ahead");
             [[maybe_unused]] const unsigned long long t0 = WXT_NOW();
             const int tl = lane_id();
@@ -486,13 +492,13 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), (XCfg<M, NH, NTW>::NW
             f32x4 afr[2][2];
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) afr[0][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE);
-            static_for<0, 12>([&](auto s_) __attribute__((always_inline)) {
-                constexpr int S_ = decltype(s_)::value, KY = S_ / 4, mt = S_ % 4;
+            static_for<0, 3 * C::MT>([&](auto s_) __attribute__((always_inline)) {
+                constexpr int S_ = decltype(s_)::value, KY = S_ / C::MT, mt = S_ % C::MT;
                 __builtin_amdgcn_sched_barrier(0);
                 {
                     const f32x4 (&b)[NTW][2] = bring[KY];
-                    if constexpr (S_ < 11) {
-                        constexpr int KY1 = (S_ + 1) / 4, mt1 = (S_ + 1) % 4;
+                    if constexpr (S_ < 3 * C::MT - 1) {
+                        constexpr int KY1 = (S_ + 1) / C::MT, mt1 = (S_ + 1) % C::MT;
 #pragma unroll
                         for (int pt = 0; pt < 2; ++pt)
                             afr[(S_ + 1) & 1][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE + (4 * mt1 + KY1) * 128);
@@ -521,7 +527,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), (XCfg<M, NH, NTW>::NW
                         item_stage(pnext, main_E(k, tl), main_active(k, tl), raw[setv][k], mid[un], std::integral_constant<int, 4 * cp + 2 + H % 2>{});
                     }
                 });
-                if constexpr (mt == 3) load_b((cb + 1) * 3 + KY, bring[KY]);      // this slab's last use was the step above
+                if constexpr (mt == C::MT - 1) load_b((cb + 1) * 3 + KY, bring[KY]);      // this slab's last use was the step above
             });
             __builtin_amdgcn_sched_barrier(0);
             [[maybe_unused]] const unsigned long long t2 = WXT_NOW();
@@ -585,7 +591,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), (XCfg<M, NH, NTW>::NW
         constexpr int EPI = decltype(epi_c)::value, ACT = decltype(act_c)::value;
         const bool has_skip = EPI == BSVD_EPI_PS_ADD && p.extra != nullptr;
 #pragma unroll
-        for (int rnd = 0; rnd < 2; ++rnd) {
+        for (int rnd = 0; rnd < C::MT / 2; ++rnd) {
             if (rnd) __syncthreads();                    // round 0's readers are done
             // publish: block (mtl, channel tile hh * NTW + nt), position xi: [4 register quads][64 lanes] x 16 B, slot XOR-swizzled
 #pragma unroll
@@ -707,12 +713,12 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW>::NTHREADS), (XCfg<M, NH, NTW>::NW
 #endif
 }
 
-template <int M, int NH, int NTW>
+template <int M, int NH, int NTW, int MT = 4>
 static int launch_winox_cfg(const ConvParams &pin, hipStream_t stream, char *name, int name_len)
 {
-    using C = XCfg<M, NH, NTW>;
+    using C = XCfg<M, NH, NTW, MT>;
     if (name) {
-        snprintf(name, name_len, "winox_kernel<F(%d,3),%dx%d>[f16x3]", M, NH, NTW);
+        snprintf(name, name_len, "winox_kernel<F(%d,3),%dx%d>[f16x3]%s", M, NH, NTW, MT == 2 ? "[8 rows]" : "");
         return 0;
     }
     ConvParams p = pin;
@@ -722,9 +728,9 @@ static int launch_winox_cfg(const ConvParams &pin, hipStream_t stream, char *nam
     const int64_t nblk = (int64_t)p.frames * p.nty * p.ntx * p.nct;
     if (nblk <= 0 || nblk > 0x7fffffff) { set_error("bsvd_conv3x3: grid of %lld workgroups", (long long)nblk); return -1; }
     static std::atomic<int> granted[MAX_DEVICES];
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&winox_kernel<M, NH, NTW>), C::LDS_BYTES, granted);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&winox_kernel<M, NH, NTW, MT>), C::LDS_BYTES, granted);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((winox_kernel<M, NH, NTW>), dim3((unsigned)nblk), dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((winox_kernel<M, NH, NTW, MT>), dim3((unsigned)nblk), dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -732,7 +738,21 @@ int launch_winox(const ConvParams &p, hipStream_t stream, char *name, int name_l
 {
     switch (p.wino_m) {
     case 22: return launch_winox_cfg<2, 1, 2>(p, stream, name, name_len);     // 4-wave workgroups, two per CU
-    case 2: return launch_winox_cfg<2, 2, 2>(p, stream, name, name_len);
+    case 32: return launch_winox_cfg<2, 2, 2, 2>(p, stream, name, name_len);  // the half-height tile whatever the grid (tests, A/B)
+    case 42: return launch_winox_cfg<2, 2, 2>(p, stream, name, name_len);     // the full tile whatever the grid: launches that share the chip with
+                                                                              // another graph branch (the lagged two-chain stream step) -- idle CUs are not idle there
+    case 2: {
+        // Small grids (single-frame launches of the stream schedules): one 8-wave workgroup per CU, so the launch takes
+        // ceil(workgroups / 256) rounds -- 270 workgroups (256 -> 256 at 135 x 240) cost two full rounds for 1.05 rounds of work.
+        // The half-height tile has twice the workgroups and computes every output with the same instruction sequence (bit-identical:
+        // stream == clip stays bitwise), at ~0.87 of the full tile's efficiency (10 patch rows per 8, prologue / epilogue per tile).
+        using C4 = XCfg<2, 2, 2, 4>;
+        const int64_t per_row = (int64_t)p.frames * ((p.Wo + C4::TWPX - 1) / C4::TWPX) * ((p.Cout + C4::BN - 1) / C4::BN);
+        const int64_t n4 = per_row * ((p.Ho + 15) / 16), n2 = per_row * ((p.Ho + 7) / 8);
+        auto fill = [](int64_t n) { return (double)n / (double)(((n + BSVD_CUS - 1) / BSVD_CUS) * BSVD_CUS); };
+        if (n4 < 8 * BSVD_CUS && 0.87 * fill(n2) > fill(n4)) return launch_winox_cfg<2, 2, 2, 2>(p, stream, name, name_len);
+        return launch_winox_cfg<2, 2, 2>(p, stream, name, name_len);
+    }
     case 4: return launch_winox_cfg<4, 2, 1>(p, stream, name, name_len);
     default: return launch_winox_cfg<6, 1, 2>(p, stream, name, name_len);
     }

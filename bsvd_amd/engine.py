@@ -35,7 +35,7 @@ def head_fusable(inc0, inc3, precision):
             and not inc3.tsm and inc3.epilogue == EPI_PLAIN and inc0.act == inc3.act)
 
 
-WIDE_CONV = ("direct", "wino2", "wino4", "wino6", "wino2b", "wino4b", "wino2s")
+WIDE_CONV = ("direct", "wino2", "wino4", "wino6", "wino2b", "wino4b", "wino2s", "wino2h")
 
 
 WINO_MIN_CIN = 128     # narrowest layer the Winograd form takes (engine.PackedNet(wino_min_cin=...))
@@ -62,8 +62,8 @@ class PackedNet:
         self.precision = precision
         self.wide_conv = wide_conv
         # F(m,3) form; the ABI's wino_m + 10 selects the all-positions-per-wave kernel (conv3x3_wino.hip, measurement variant)
-        self.wino_m = {"direct": 0, "wino2": 2, "wino4": 4, "wino6": 6, "wino2b": 2, "wino4b": 4, "wino2s": 2}[wide_conv]
-        self.wino_abi = self.wino_m + (10 if wide_conv.endswith("b") else 20 if wide_conv.endswith("s") else 0)
+        self.wino_m = {"direct": 0, "wino2": 2, "wino4": 4, "wino6": 6, "wino2b": 2, "wino4b": 4, "wino2s": 2, "wino2h": 2}[wide_conv]
+        self.wino_abi = self.wino_m + (10 if wide_conv.endswith("b") else 20 if wide_conv.endswith("s") else 30 if wide_conv.endswith("h") else 0)
         self.wino_min_cin = int(os.environ.get("BSVD_WINO_MIN_CIN", WINO_MIN_CIN)) if wino_min_cin is None else int(wino_min_cin)
         self.wino = {}               # {spec.key: transformed pack} of the layers that run on the Winograd kernel
         self.tensors = {}
@@ -135,6 +135,7 @@ class HipExecutor:
         # tuning override of the direct form's fat-tile threshold (BsvdConvArgs.fat_min_wgs; 0 = library default).  Read HERE, on the
         # host side of the ABI, once per executor -- the library itself reads no environment
         self.fat_min_wgs = int(os.environ.get("BSVD_FAT_MIN_WGS", "0") or 0)
+        self.wino_full_tile = False  # build_args: F(2,3) launches never take the half-height tile (set by the two-branch stream step)
         self.record_variants = False     # profiling aid: ask the library which kernel instantiation each conv uses
         self.last_variant = None
 
@@ -298,6 +299,8 @@ class HipExecutor:
             a.w_packed = wp.data_ptr()
         else:
             a.w_wino_packed, a.wino_m = self.packed.wino[sp.key].data_ptr(), self.packed.wino_abi
+            if self.wino_full_tile and a.wino_m == 2:
+                a.wino_m = 42         # this launch shares the chip with another graph branch: never the half-height tile (same bits)
         if extra is not None:
             a.extra = extra.data_ptr()
             a.extra_frame_stride = extra[0].numel()

@@ -116,7 +116,10 @@ typedef struct BsvdConvArgs {
     const void *head_bias;
     /* Winograd form of a wide layer (ABI v9, BSVD_F16X3 only).  w_wino_packed != NULL selects the 1-D Winograd F(wino_m, 3)
      * kernel (wino_m = 2, 4 or 6; conv3x3_winox.hip, one transformed position per wave; wino_m + 10 = 12 | 14 runs the
-     * all-positions-per-wave variant conv3x3_wino.hip on the same F(2,3) / F(4,3) pack -- kept for measurements) with the
+     * all-positions-per-wave variant conv3x3_wino.hip on the same F(2,3) / F(4,3) pack, 22 / 32 force F(2,3)'s 4-wave workgroup /
+     * its half-height tile -- kept for measurements and tests; wino_m = 2 picks the half-height tile itself for grids that
+     * do not fill the chip, bit-identical to the full tile, and 42 = F(2,3) always on the full tile is for launches that run
+     * beside another stream's or graph branch's kernels) with the
      * TRANSFORMED weights of bsvd_pack_weights_wino(); w_packed is then
      * ignored (may be NULL).  Same contract and tensors as the direct form -- gather, halos, bias, activation, PLAIN / PS_ADD
      * epilogues -- but 6 (F(2,3)), 4.5 (F(4,3)) or 4 (F(6,3)) instead of 9 tap-GEMMs per output pixel; results differ from the direct

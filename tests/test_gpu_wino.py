@@ -36,7 +36,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("wide_conv", ["wino2", "wino4", "wino6", "wino2b", "wino2s"])
+@pytest.mark.parametrize("wide_conv", ["wino2", "wino4", "wino6", "wino2b", "wino2s", "wino2h"])
 @pytest.mark.parametrize("cin,cout,tsm,act,epi,T,H,W", CASES)
 def test_wino_layer_vs_oracle(wide_conv, cin, cout, tsm, act, epi, T, H, W):
     from bsvd_amd.netspec import ConvSpec
@@ -73,6 +73,37 @@ def test_wino_layer_vs_oracle(wide_conv, cin, cout, tsm, act, epi, T, H, W):
         err = maxabs(got.numpy(), want.numpy())
         print("%s layer %s max-abs %.3e (|y| max %.1f)" % (wide_conv, (cin, cout, tsm, epi, T, H, W), err, float(want.abs().max())))
         assert err < TIGHT
+
+
+def test_half_height_tile_is_bit_identical_and_taken_by_grids_that_do_not_fill_the_chip():
+    """wino_m = 2 launches the 8-row tile when the 16-row grid would leave CUs idle (single-frame launches of the stream schedules:
+    256 -> 256 at 135 x 240 is 270 workgroups on 256 CUs); both tiles run the same instruction sequence per output, so the choice --
+    which depends on the launch's size -- cannot break stream == clip (bsvd_arch.py:485-552 vs :555-569)."""
+    from bsvd_amd.netspec import ConvSpec
+    rs = np.random.RandomState(5)
+    outs = {}
+    for cin, H, W, want_half in ((128, 270, 480, False), (256, 135, 240, True)):
+        sp = ConvSpec("l", "l", cin, cin, 1, True, "relu6", 0)
+        st = seeded_state([("e0.weight", (16, 4, 3, 3)), ("e0.bias", (16,)), ("l.weight", (cin, cin, 3, 3)),
+                           ("l.bias", (cin,)), ("e1.weight", (3, 16, 3, 3)), ("e1.bias", (3,))], 7)
+        x = to_split(torch.from_numpy(rs.standard_normal((1, H, W, cin)).astype(np.float32))).to(_dev())
+        for form in ("wino2", "wino2h"):
+            gex = _exec(_Net(sp), st, form)
+            gex.record_variants = True
+            outs[form] = gex.conv(sp, x).clone()
+            half = gex.last_variant.endswith("[8 rows]")
+            assert half == (want_half or form == "wino2h"), (form, cin, gex.last_variant)
+        assert torch.equal(outs["wino2"], outs["wino2h"])
+        if want_half:       # ... and a 10-frame clip of the same layer takes the full tile and produces the same bits per frame
+            gex = _exec(_Net(sp), st, "wino2")
+            gex.record_variants = True
+            from bsvd_amd.schedule import Halo
+            x10 = x.expand(10, -1, -1, -1).contiguous()
+            y10 = gex.conv(sp, x10)
+            assert not gex.last_variant.endswith("[8 rows]"), gex.last_variant
+            y1 = gex.conv(sp, x, Halo(x, cin, sp.fold), Halo(x, cin, 0))     # frame 5's neighbours = the same frame
+            assert gex.last_variant.endswith("[8 rows]")
+            assert torch.equal(y10[5:6], y1)
 
 
 @pytest.mark.parametrize("wide_conv", ["wino2", "wino6"])

@@ -22,10 +22,16 @@ def kernel_key(name):
         return "conv3x3_kernel<%s,%s,%s,%s,%s>%s%s%s%s" % (mt, nt, wm, wn, st, "[f16x3]" if prec == "1" else "[f32]",
                                                           ("[fold8]" if mix == "true" else "") if fast == "true" else "[generic]",
                                                           planar, "[fused entry]" if headf == "true" else "")
+    m = re.search(r"winox_kernel<(\d+), (\d+), (\d+), (\d+)>", name)
+    if m:
+        return "winox_kernel<F(%s,3),%sx%s>[f16x3]" % m.groups()[:3] + ("[8 rows]" if m.group(4) == "2" else "")
+    m = re.search(r"wino_kernel<(\d+)>", name)
+    if m:
+        return "wino_kernel<F(%s,3)>[f16x3]" % m.group(1)
     m = re.search(r"(head|tail)_kernel<(\d)>", name)
     if m:
         return m.group(0)          # bench.py appends the mode tag; match on the prefix
-    for k in ("pack_weights_split_kernel", "pack_weights_kernel", "nchw_to_nhwc_kernel",
+    for k in ("pack_weights_wino_kernel", "pack_weights_split_kernel", "pack_weights_kernel", "nchw_to_nhwc_kernel",
               "nhwc_to_nchw_kernel", "halo_pack_kernel"):
         if k in name:
             return k
