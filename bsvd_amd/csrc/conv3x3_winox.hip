@@ -46,7 +46,7 @@
 #define BSVD_WX_ILV_VALU 2 // VALU instructions per MFMA in the interleave pipeline
 #endif
 #ifndef BSVD_WX_ABL
-#define BSVD_WX_ABL 0      // TIMING-ONLY ablations (results wrong): 1 no transform in the K loop, 2 no MFMA steps, 4 no epilogue finish, 8 no chunk barrier, 16 transform without its global loads, 32 transform without its LDS stores
+#define BSVD_WX_ABL 0      // TIMING-ONLY ablations (results wrong): 1 no transform in the K loop, 2 no MFMA steps, 4 no epilogue finish, 8 no chunk barrier, 16 transform without its global loads (constant operands: also removes operand toggling), 32 transform without its LDS stores, 64 the K loop re-transforms the prologue's raw registers (no activation loads in the loop, realistic operand values)
 #endif
 
 namespace bsvd {
@@ -246,9 +246,11 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW,
     };
 
     // ---- transform items.  CH channels of one patch slot (row, group) per item:
-    //        CH = 4 (768-thread workgroups): E = row * 32 + qb * 16 + group * 2 + half        -> channels 8 qb + 4 half .. + 3, 8-byte loads
-    //        CH = 2 (512-thread workgroups): E = row * 64 + qb * 32 + group * 4 + pr          -> channels 8 qb + 2 pr, + 1,     4-byte loads
-    //      (consecutive lanes cover consecutive bytes of a slot, then consecutive slots: 4-byte LDS stores of 32 lanes hit 32 banks.)
+    //        CH = 4 (768-thread workgroups): E = row * 32 + group * 4 + qb * 2 + half         -> channels 8 qb + 4 half .. + 3, 8-byte loads
+    //        CH = 2 (512-thread workgroups): E = row * 64 + group * 8 + qb * 4 + pr           -> channels 8 qb + 2 pr, + 1,     4-byte loads
+    //      (consecutive lanes cover the 32 contiguous bytes of a pixel's hi -- or lo -- halves, then the next group: a load instruction
+    //       touches 8 lines for 32 B each.  Quarter-major, 16 B per line and instruction, the texture addresser was as busy as the
+    //       matrix pipe: 4608 line accesses per chunk of F(6,3) against 4608 MFMA cycles; BSVD_WX_EMAP)
     //      An item is LOADED one chunk before it is FINISHED (decode, BT, re-split, LDS stores): the raw registers ride through the
     //      MFMA steps in between, so that no wave ever waits for the activation tensor (1-3 us away) with nothing else to issue.
     //      Rows outside the image need no mask -- their byte offsets fall outside the buffer descriptor (negative rows wrap to > 2 GiB),
@@ -258,12 +260,45 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW,
     constexpr int CH = C::NTHREADS == 512 ? 2 : 4;
     constexpr int NDW = CH / 2;                                   // dwords per pixel and part
     struct Raw { unsigned h[A][NDW], l[A][NDW]; };
+#ifndef BSVD_WX_EMAP
+#define BSVD_WX_EMAP 1     // item -> lane order: 1 the two 8-channel quarters of a slot on ADJACENT lanes (8 (4) consecutive lanes read 32 contiguous
+                           // bytes of one pixel: half the lines per load instruction), 0 quarter-major (16 bytes per line and instruction)
+#endif
+#ifndef BSVD_WX_XIN
+#define BSVD_WX_XIN 1      // scalar position offsets for tiles whose patch columns are all inside the image (item_load)
+#endif
+    const bool x_inside = ox0 >= 1 && ox0 + C::TWPX + 1 <= p.W;      // wave uniform
+    auto item_geom = [](int E, int &row, int &qb, int &g, int &sub) __attribute__((always_inline)) {
+        if constexpr (CH == 4) {
+            row = E >> 5; sub = (E & 1) * 8;
+            if constexpr (BSVD_WX_EMAP) { g = (E >> 2) & 7; qb = (E >> 1) & 1; } else { qb = (E >> 4) & 1; g = (E >> 1) & 7; }
+        } else {
+            row = E >> 6; sub = (E & 3) * 4;
+            if constexpr (BSVD_WX_EMAP) { g = (E >> 3) & 7; qb = (E >> 2) & 1; } else { qb = (E >> 5) & 1; g = (E >> 2) & 7; }
+        }
+    };
     auto item_load = [&](const XChunkSrc &c, int E, bool active, Raw &r) __attribute__((always_inline)) {
         int row, qb, g, sub;
-        if constexpr (CH == 4) { row = E >> 5; qb = (E >> 4) & 1; g = (E >> 1) & 7; sub = (E & 1) * 8; }
-        else                   { row = E >> 6; qb = (E >> 5) & 1; g = (E >> 2) & 7; sub = (E & 3) * 4; }
+        item_geom(E, row, qb, g, sub);
         const int gx0 = ox0 - 1 + M * g;
         const unsigned base = active ? (unsigned)((oy0 - 1 + row) * p.W + gx0) * c.ps4 + (unsigned)(qb * 16 + sub) : BSVD_WX_OOB;
+        if (BSVD_WX_XIN && x_inside) {
+            // every column of the patch is inside the image (all tiles but the first and last of a tile row): the A positions differ by a
+            // SCALAR offset -- one address register per item, no compare / select per position (3 VALU each; with the compares the address
+            // arithmetic was a fifth of the transform's instructions).  Rows still need nothing: the range check is on the vector offset.
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                const unsigned so = c.soff + (unsigned)i * c.ps4;
+                if constexpr (CH == 4) {
+                    const u32x2 hv = buf_load2(c.rs, base, so), lv = buf_load2(c.rs, base, so + 32u);
+                    r.h[i][0] = hv[0]; r.h[i][NDW - 1] = hv[1]; r.l[i][0] = lv[0]; r.l[i][NDW - 1] = lv[1];
+                } else {
+                    r.h[i][0] = __builtin_amdgcn_raw_buffer_load_b32(c.rs, base, so, 0);
+                    r.l[i][0] = __builtin_amdgcn_raw_buffer_load_b32(c.rs, base, so + 32u, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A; ++i) {
             const unsigned voff = (unsigned)(gx0 + i) < (unsigned)p.W ? base + (unsigned)i * c.ps4 : BSVD_WX_OOB;
@@ -281,8 +316,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW,
     };
     auto item_finish = [&](unsigned char *vbuf, int E, bool active, const Raw &r) __attribute__((always_inline)) {
         int row, qb, g, sub;
-        if constexpr (CH == 4) { row = E >> 5; qb = (E >> 4) & 1; g = (E >> 1) & 7; sub = (E & 1) * 8; }
-        else                   { row = E >> 6; qb = (E >> 5) & 1; g = (E >> 2) & 7; sub = (E & 3) * 4; }
+        item_geom(E, row, qb, g, sub);
         unsigned char *dst = vbuf + qb * C::PLANE + (row * 8 + g) * 16 + sub;
 #pragma unroll
         for (int cp = 0; cp < NDW; ++cp) {            // a channel pair = one dword per position and part
@@ -318,8 +352,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW,
             F::input(d, m.v[q]);
         } else {
             int row, qb, g, sub;
-            if constexpr (CH == 4) { row = E >> 5; qb = (E >> 4) & 1; g = (E >> 1) & 7; sub = (E & 1) * 8; }
-            else                   { row = E >> 6; qb = (E >> 5) & 1; g = (E >> 2) & 7; sub = (E & 3) * 4; }
+            item_geom(E, row, qb, g, sub);
             unsigned char *dst = vbuf + qb * C::PLANE + (row * 8 + g) * 16 + sub;
 #pragma unroll
             for (int i = (q - 2) * (A / 2); i < (q - 1) * (A / 2); ++i) {
@@ -464,7 +497,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW,
             if (BSVD_WX_PRIO) __builtin_amdgcn_s_setprio(BSVD_WX_PRIO);
             const int tl = lane_id();
             chunk_finish(cb + 1, pnext, setv, PAll{}, tl);
-            chunk_load(cb + 1 + PP, setv, PAll{}, tl);
+            if (!(BSVD_WX_ABL & 64)) chunk_load(cb + 1 + PP, setv, PAll{}, tl);
             if (BSVD_WX_PRIO) __builtin_amdgcn_s_setprio(0);
         };
         // (one copy of the MFMA steps between two conditional transforms: an if / else with the phases in opposite orders made the
