@@ -36,6 +36,9 @@
 #include "wino_forms.h"
 
 #define BSVD_WX_OOB 0x7fffffffu
+#ifndef BSVD_WX_PERSIST_MIN
+#define BSVD_WX_PERSIST_MIN (1 << 20)   // tiles per CU from which F(2,3) launches take the persistent form.  Measured SLOWER: never, by default
+#endif
 #define BSVD_CUS 256       // MI355X: 256 CUs, one 8-wave workgroup of this kernel each (the tile choice of small grids, launch_winox)
 #ifndef BSVD_WX_ILV
 #define BSVD_WX_ILV 0      // 1: the transform of the next chunk is interleaved INTO each wave's own MFMA stream (sched_group_barrier pipeline) instead of
@@ -78,8 +81,9 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-template <int M_, int NH_, int NTW_, int MT_ = 4>
+template <int M_, int NH_, int NTW_, int MT_ = 4, bool PERSIST_ = false>
 struct XCfg {
+    static constexpr bool PERSIST = PERSIST_;     // one workgroup per CU walks a list of tiles; the transform pipeline runs across tile boundaries
     static constexpr int M = M_, A = M + 2, NH = NH_, NTW = NTW_;
     static constexpr int NW = A * NH, NTHREADS = NW * 64;
     static constexpr int MT = MT_;                // MFMA tiles of the pixel tile: 8 groups x 4 rows each.  MT = 2: the half-height tile small grids
@@ -91,14 +95,19 @@ struct XCfg {
     static constexpr int V_BUF = A * 4 * PLANE;
     static constexpr int NITEM = NSLOT * 4;       // transform items (row, group, 4 channels) per chunk: 576
     static constexpr int BN = NH * NTW * 32;      // output channels per workgroup
-    // epilogue exchange: per round the tiles of 2 MFMA tiles x (NH NTW) channel tiles x A positions, 4 KB each
-    static constexpr int NBP = 2 * NH * NTW;      // blocks per round
+    // epilogue exchange: per round the tiles of MTL MFMA tiles x (NH NTW) channel tiles x A positions, 4 KB each.  It aliases the V
+    // buffers -- except in the persistent form, where the next tile's first chunk is already transformed when the epilogue runs:
+    // there it sits behind them, and holds one MFMA tile per round so that everything fits 160 KB
+    static constexpr int MTL = PERSIST ? 1 : 2;
+    static constexpr int NRND = MT / MTL;
+    static constexpr int NBP = MTL * NH * NTW;    // blocks per round
     static constexpr int XCH_BYTES = NBP * A * 4096;
-    static constexpr int LDS_BYTES = 2 * V_BUF > XCH_BYTES ? 2 * V_BUF : XCH_BYTES;
+    static constexpr int XCH_OFF = PERSIST ? 2 * V_BUF : 0;
+    static constexpr int LDS_BYTES = PERSIST ? 2 * V_BUF + XCH_BYTES : (2 * V_BUF > XCH_BYTES ? 2 * V_BUF : XCH_BYTES);
     static constexpr int NPART = NW / NBP >= 2 ? 2 : 1;          // finishers per block (column ranges)
     static_assert(LDS_BYTES <= 160 * 1024 && NW * 64 <= 1024 && NW % 4 == 0 && NW >= NBP, "");
     static_assert(MT == 4 || (MT == 2 && NTHREADS != 768), "item map of the half-height tile: 512- and 256-thread workgroups");
-    static constexpr int WGS = LDS_BYTES <= 80 * 1024 && NW == 4 ? 2 : 1;      // workgroups per CU
+    static constexpr int WGS = LDS_BYTES <= 80 * 1024 && NW == 4 && !PERSIST ? 2 : 1;      // workgroups per CU
     static constexpr int NPH = NW / 4 > 1 ? NW / 4 : 2;   // waves per SIMD = phases of the chunk schedule (4-wave workgroups: waves 0-1 / 2-3)
 };
 
@@ -141,9 +150,11 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned &hp, uns
     lp = __builtin_bit_cast(unsigned, lv);
 }
 
-struct XChunkSrc {         // wave-uniform source of one 16-channel chunk (temporal-shift gather: next / previous / this frame)
+struct XChunkSrc {         // wave-uniform source of one 16-channel chunk (temporal-shift gather: next / previous / this frame) + its tile's origin
     __amdgpu_buffer_rsrc_t rs;
     unsigned ps4, soff;
+    int oy0, ox0;
+    bool x_inside;
 };
 // The three temporal sources of a frame as plain scalars.  (chunk_src as a lambda over ready-made descriptors made hipcc keep a
 // table of them -- and, one nesting level later, the kernel parameters -- in private memory: a free function over a POD passed by
@@ -153,10 +164,17 @@ struct XSources {
     unsigned cur_bytes, prev_bytes, next_bytes, cur_ps4, prev_ps4, next_ps4;
     int prev_co, next_co, fold, ncb, zs_a, zs_b, zs_c;      // zs_*: zero-chunk skip (live -> full chunk index)
 };
+struct XTile {             // one tile of a workgroup's list, wave uniform (a dead tile -- beyond the list -- has zero-size sources and ncb = 0)
+    XSources S;
+    int oy0, ox0, n0, f;
+    bool x_inside;         // every column of the patch is inside the image
+};
 __device__ __forceinline__ int x_full_chunk(const XSources &s, int cbl) { return cbl + s.zs_a + (cbl >= s.zs_b ? s.zs_c : 0); }
-__device__ __forceinline__ XChunkSrc x_chunk_src(const XSources s, int cbl)      // cbl: LIVE chunk index; beyond the last: zero-size descriptor
+__device__ __forceinline__ XChunkSrc x_chunk_src(const XTile t, int cbl)      // cbl: LIVE chunk index; beyond the last: zero-size descriptor
 {
+    const XSources &s = t.S;
     XChunkSrc c;
+    c.oy0 = t.oy0; c.ox0 = t.ox0; c.x_inside = t.x_inside;
     const int c0 = x_full_chunk(s, cbl) * 16;
     const bool isn = c0 < s.fold, isp = !isn && c0 < 2 * s.fold;
     const float *base = isn ? s.nxt : isp ? s.prv : s.cur;
@@ -170,10 +188,10 @@ __device__ __forceinline__ XChunkSrc x_chunk_src(const XSources s, int cbl)     
 
 }  // namespace
 
-template <int M, int NH, int NTW, int MT>
-__global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW, MT>::NW / 4 * XCfg<M, NH, NTW, MT>::WGS)) void winox_kernel(const ConvParams p)
+template <int M, int NH, int NTW, int MT, bool PERSIST>
+__global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M, NH, NTW, MT, PERSIST>::NW / 4 * XCfg<M, NH, NTW, MT, PERSIST>::WGS)) void winox_kernel(const ConvParams p)
 {
-    using C = XCfg<M, NH, NTW, MT>;
+    using C = XCfg<M, NH, NTW, MT, PERSIST>;
     using F = WinoForm<M>;
     constexpr int A = C::A;
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
@@ -186,62 +204,96 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW,
     const int xi = wid % A, hh = wid / A;
     const int li = lane & 31, lh = lane >> 5;
 
-    // ---- block -> (frame, tile y, tile x, channel tile); XCD-aware like the direct kernel (block b runs on XCD b % 8)
-    const int nblk = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q8 = nblk >> 3, r8 = nblk & 7;
-    int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    if (p.flip) lid = nblk - 1 - lid;
-    const int ct = lid % p.nct; lid /= p.nct;
-    const int tx = lid % p.ntx; lid /= p.ntx;
-    const int ty = lid % p.nty;
-    const int f = lid / p.nty;
-    const int oy0 = ty * C::TR, ox0 = tx * C::TWPX;
-    const int n0 = ct * C::BN;
-
-    // ---- temporal sources of this frame (wave uniform)
-    const float *cur = p.x + (int64_t)f * p.x_fs;
-    const float *prv, *nxt;
-    int prev_ps, prev_co, next_ps, next_co;
-    if (f > 0) { prv = cur - p.x_fs; prev_ps = p.Cin; prev_co = p.fold; }
-    else       { prv = p.halo_prev; prev_ps = p.halo_prev_ps; prev_co = p.halo_prev_co; }
-    if (f + 1 < p.frames) { nxt = cur + p.x_fs; next_ps = p.Cin; next_co = 0; }
-    else                  { nxt = p.halo_next; next_ps = p.halo_next_ps; next_co = p.halo_next_co; }
-    // zero-chunk skip (bit-identical): the temporal-shift group of a frame whose neighbour does not exist is all zeros
-    int ncb = p.Cin >> 4;
-    int zs_a = 0, zs_b = 1 << 20, zs_c = 0;
-    if (p.fold >= 16) {
-        const int f16 = p.fold >> 4;
-        zs_b = f16;
-        if (nxt == nullptr) zs_a = f16;
-        if (prv == nullptr) zs_c = f16;
-        zs_b -= zs_a;
-        ncb -= zs_a + zs_c;
-    }
+    // ---- workgroup -> tiles (frame, tile y, tile x, channel tile), XCD-aware like the direct kernel: block b runs on XCD b % 8 and
+    //      every XCD owns one contiguous range of the tile list (neighbouring tiles share halo rows and weights in that XCD's L2).
+    //      One tile per workgroup -- or, PERSIST, the workgroups of an XCD deal its range among themselves round robin.
+    const int ntiles = p.frames * p.nty * p.ntx * p.nct;
+    const int bid = blockIdx.x, xcd = bid & 7;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int xcd_first = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, xcd_count = q8 + (xcd < r8 ? 1 : 0);
+    const int xcd_wgs = ((int)gridDim.x - xcd + 7) >> 3;      // workgroups of this launch on this XCD (== xcd_count when not persistent)
     const unsigned hw = (unsigned)p.H * (unsigned)p.W;
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)p.Cin * (unsigned)(3 * A) * (unsigned)p.Cout * 4u);
-    XSources S;
-    S.cur = cur; S.prv = prv ? prv : cur; S.nxt = nxt ? nxt : cur;
-    S.cur_bytes = hw * p.Cin * 4u; S.prev_bytes = prv ? hw * prev_ps * 4u : 0u; S.next_bytes = nxt ? hw * next_ps * 4u : 0u;
-    S.cur_ps4 = p.Cin * 4u; S.prev_ps4 = prev_ps * 4u; S.next_ps4 = next_ps * 4u;
-    S.prev_co = prev_co; S.next_co = next_co; S.fold = p.fold; S.ncb = ncb; S.zs_a = zs_a; S.zs_b = zs_b; S.zs_c = zs_c;
+    auto decode_tile = [&](int j) __attribute__((always_inline)) {      // j: index into this XCD's range; beyond it: a dead tile
+        XTile t;
+        const bool live = j < xcd_count;
+        int lid = xcd_first + (live ? j : 0);
+        if (p.flip) lid = ntiles - 1 - lid;
+        const int ct = lid % p.nct; lid /= p.nct;
+        const int tx = lid % p.ntx; lid /= p.ntx;
+        const int ty = lid % p.nty;
+        const int f = lid / p.nty;
+        t.f = f; t.oy0 = ty * C::TR; t.ox0 = tx * C::TWPX; t.n0 = ct * C::BN;
+        t.x_inside = t.ox0 >= 1 && t.ox0 + C::TWPX + 1 <= p.W;
+        // temporal sources of this frame
+        const float *cur = p.x + (int64_t)f * p.x_fs;
+        const float *prv, *nxt;
+        int prev_ps, prev_co, next_ps, next_co;
+        if (f > 0) { prv = cur - p.x_fs; prev_ps = p.Cin; prev_co = p.fold; }
+        else       { prv = p.halo_prev; prev_ps = p.halo_prev_ps; prev_co = p.halo_prev_co; }
+        if (f + 1 < p.frames) { nxt = cur + p.x_fs; next_ps = p.Cin; next_co = 0; }
+        else                  { nxt = p.halo_next; next_ps = p.halo_next_ps; next_co = p.halo_next_co; }
+        // zero-chunk skip (bit-identical): the temporal-shift group of a frame whose neighbour does not exist is all zeros
+        int ncb = p.Cin >> 4;
+        int zs_a = 0, zs_b = 1 << 20, zs_c = 0;
+        if (p.fold >= 16) {
+            const int f16 = p.fold >> 4;
+            zs_b = f16;
+            if (nxt == nullptr) zs_a = f16;
+            if (prv == nullptr) zs_c = f16;
+            zs_b -= zs_a;
+            ncb -= zs_a + zs_c;
+            // the persistent pipeline alternates two V buffers and two raw register sets by chunk parity across tile boundaries:
+            // every tile walks an EVEN number of chunks (an odd count keeps its zero chunk; same bits)
+            if (PERSIST && (ncb & 1)) { zs_a = 0; zs_c = 0; zs_b = 1 << 20; ncb = p.Cin >> 4; }
+        }
+        XSources &S = t.S;
+        S.cur = cur; S.prv = prv ? prv : cur; S.nxt = nxt ? nxt : cur;
+        S.cur_bytes = live ? hw * p.Cin * 4u : 0u; S.prev_bytes = prv && live ? hw * prev_ps * 4u : 0u; S.next_bytes = nxt && live ? hw * next_ps * 4u : 0u;
+        S.cur_ps4 = p.Cin * 4u; S.prev_ps4 = prev_ps * 4u; S.next_ps4 = next_ps * 4u;
+        S.prev_co = prev_co; S.next_co = next_co; S.fold = p.fold; S.ncb = live ? ncb : 0; S.zs_a = zs_a; S.zs_b = zs_b; S.zs_c = zs_c;
+        return t;
+    };
+    int jt = bid >> 3;
+    XTile T = decode_tile(jt);
+    // The workgroup's NEXT tile (dead when there is none) is decoded where it is needed -- the requests of the last PP + 1 chunks of a
+    // tile and its last weight slabs: ~3 times per tile, a few dozen scalar instructions each.
+    // (PERSIST, as built: hipcc hoists the kernel parameters and the epilogues' lane constants out of the tile loop, runs out of scalar
+    //  registers -- 140 v_writelane / 2200 v_readlane -- and spills ~20 vector registers; a scratch reload in the epilogue waits, through
+    //  the in-order vmcnt, for the previous round's stores.  A tile table in LDS read back with v_readfirstlane removed the scalar spills
+    //  and cost more than it saved (the reads' lgkmcnt(0) waits sit inside the MFMA steps).  Measured 6-13 % slower than one tile per
+    //  workgroup; kept for the record, never selected: BSVD_WX_PERSIST_MIN.)
+    auto next_tile = [&]() __attribute__((always_inline)) { return decode_tile(PERSIST ? jt + xcd_wgs : 0x3fffffff); };
+    const unsigned w_bytes = (unsigned)p.Cin * (unsigned)(3 * A) * (unsigned)p.Cout * 4u;
 
     // ---- weights of this wave's position: rows of the MFMA's A operand = output channels (conv3x3_mfma.hip: `chan`)
     const int rrow = (li & 3) + 4 * (li >> 3);
     const int chan = 8 * (2 * (rrow >> 3) + ((li >> 2) & 1)) + (rrow & 7);
-    const int nb0 = n0 + hh * (NTW * 32) + chan;
     const unsigned slab_bytes = 64u * p.Cout, g_bytes = 32u * p.Cout;
-    unsigned vb[NTW];
+    unsigned vb[NTW];          // lane part of the address (tile independent); the channel tile's n0 rides in the scalar offset
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) vb[nt] = nb0 + 32 * nt < p.Cout ? (unsigned)(lh * p.Cout + nb0 + 32 * nt) * 16u : BSVD_WX_OOB;
-    const int nsteps = ncb * 3;
-    auto load_b = [&](int step, f32x4 (&b)[NTW][2]) __attribute__((always_inline)) {     // step = live chunk * 3 + ky
-        step = step < nsteps ? step : nsteps - 1;
-        const int cbl = step / 3, ky = step - 3 * cbl;
-        const unsigned so = (unsigned)((x_full_chunk(S, cbl) * A + xi) * 3 + ky) * slab_bytes;
+    for (int nt = 0; nt < NTW; ++nt) vb[nt] = (unsigned)(lh * p.Cout + hh * (NTW * 32) + chan + 32 * nt) * 16u;
+    // step = live chunk * 3 + ky of tile T; beyond T's last step: the first steps of Tn (a dead Tn: any valid slab)
+    auto load_b = [&](int step, f32x4 (&b)[NTW][2]) __attribute__((always_inline)) {
+        const int ns0 = T.S.ncb * 3;
+        int n0, fcb, ky;        // channel tile, full chunk index and kernel row of the slab
+        if (step >= ns0) {
+            const XTile tn = next_tile();
+            int st = step - ns0;
+            const int nst = tn.S.ncb * 3;
+            st = st < nst ? st : (nst > 0 ? nst - 1 : 0);
+            const int cbl = st / 3;
+            n0 = tn.n0; fcb = x_full_chunk(tn.S, cbl); ky = st - 3 * cbl;
+        } else {
+            const int cbl = step / 3;
+            n0 = T.n0; fcb = x_full_chunk(T.S, cbl); ky = step - 3 * cbl;
+        }
+        const unsigned so = (unsigned)((fcb * A + xi) * 3 + ky) * slab_bytes + (unsigned)n0 * 16u;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-            b[nt][0] = buf_load4(rs_w, vb[nt], so);
-            b[nt][1] = buf_load4(rs_w, vb[nt], so + g_bytes);
+            // (a channel tile beyond Cout: a zero-size descriptor -- a scalar select, no per-lane address register)
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.w, n0 + hh * (NTW * 32) + 32 * nt < p.Cout ? w_bytes : 0u);
+            b[nt][0] = buf_load4(rs, vb[nt], so);
+            b[nt][1] = buf_load4(rs, vb[nt], so + g_bytes);
         }
     };
 
@@ -267,7 +319,6 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW,
 #ifndef BSVD_WX_XIN
 #define BSVD_WX_XIN 1      // scalar position offsets for tiles whose patch columns are all inside the image (item_load)
 #endif
-    const bool x_inside = ox0 >= 1 && ox0 + C::TWPX + 1 <= p.W;      // wave uniform
     auto item_geom = [](int E, int &row, int &qb, int &g, int &sub) __attribute__((always_inline)) {
         if constexpr (CH == 4) {
             row = E >> 5; sub = (E & 1) * 8;
@@ -280,9 +331,9 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW,
     auto item_load = [&](const XChunkSrc &c, int E, bool active, Raw &r) __attribute__((always_inline)) {
         int row, qb, g, sub;
         item_geom(E, row, qb, g, sub);
-        const int gx0 = ox0 - 1 + M * g;
-        const unsigned base = active ? (unsigned)((oy0 - 1 + row) * p.W + gx0) * c.ps4 + (unsigned)(qb * 16 + sub) : BSVD_WX_OOB;
-        if (BSVD_WX_XIN && x_inside) {
+        const int gx0 = c.ox0 - 1 + M * g;
+        const unsigned base = active ? (unsigned)((c.oy0 - 1 + row) * p.W + gx0) * c.ps4 + (unsigned)(qb * 16 + sub) : BSVD_WX_OOB;
+        if (BSVD_WX_XIN && c.x_inside) {
             // every column of the patch is inside the image (all tiles but the first and last of a tile row): the A positions differ by a
             // SCALAR offset -- one address register per item, no compare / select per position (3 VALU each; with the compares the address
             // arithmetic was a fifth of the transform's instructions).  Rows still need nothing: the range check is on the vector offset.
@@ -389,18 +440,26 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW,
     auto main_active = [&](int k, int tl) __attribute__((always_inline)) {
         return C::NTHREADS == 768 ? tl < 48 : k < NFULL ? true : tl < 64 * (C::NTHREADS == 512 ? 2 : 1) / C::NW;
     };
+    int rot_base = 0;          // chunks of the workgroup's earlier tiles: the rotation runs on across tiles (a chunk is requested under one tile's
+                               // numbering and finished under the next one's)
     auto rot_slot = [&](int cc) __attribute__((always_inline)) {                // 0 / 1: this wave takes left-over block 0 / 1 of chunk cc, -1: none
         if constexpr (NROT == 0) return -1;
-        const int d = (wid - cc % C::NW + C::NW) % C::NW;
+        const int d = (wid - (cc + rot_base) % C::NW + C::NW) % C::NW;
         return d < NROT ? d : -1;
     };
     // PP raw register sets: chunk cc's items live in set cc % PP.  PP = 2 where the registers are there (F(2,3)): an item is then
     // requested TWO chunks before it is finished
-    constexpr int PP = (M == 2 && C::NTHREADS == 512 && BSVD_WX_ILV != 2) ? 2 : 1;
+#ifndef BSVD_WX_PP_PERSIST
+#define BSVD_WX_PP_PERSIST 1   // raw register sets of the persistent form
+#endif
+    constexpr int PP = (M == 2 && C::NTHREADS == 512 && BSVD_WX_ILV != 2) ? (PERSIST ? BSVD_WX_PP_PERSIST : 2) : 1;
     Raw raw[PP][NMAIN], raw_rot[PP];
     using PAll = std::integral_constant<int, 3>;     // part_: 1 the lanes' main items, 2 the rotating left-over block, 3 both
     auto chunk_load = [&](int cc, int SET, auto part_, int tl) __attribute__((always_inline)) {
-        const XChunkSrc c = x_chunk_src(S, cc);       // beyond the last chunk: zero-size descriptor, zeros, never read
+        // beyond T's last chunk: the first chunks of the workgroup's next tile (or of a dead tile: zeros)
+        XChunkSrc c;
+        if (cc >= T.S.ncb) c = x_chunk_src(next_tile(), cc - T.S.ncb);
+        else c = x_chunk_src(T, cc);
         if constexpr (decltype(part_)::value & 1) {
 #pragma unroll
         for (int k = 0; k < NMAIN; ++k) item_load(c, main_E(k, tl), main_active(k, tl), raw[SET][k]);
@@ -421,16 +480,8 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW,
         }
     };
 
-    // ---- accumulators
+    // ---- prologue (of the workgroup's first tile; a later tile's first chunk is transformed under its predecessor's last MFMA steps)
     f32x16 acc[C::MT][NTW];
-#pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-    // ---- prologue
     f32x4 bring[3][NTW][2];
     load_b(0, bring[0]);
     load_b(1, bring[1]);
@@ -449,6 +500,15 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW,
     // (the loop body is written out in the loop, not as a lambda: one more level of by-reference closure nesting and hipcc no longer
     //  promotes the captured locals -- kernel parameters, pointers, the raw sets -- out of private memory)
     [[maybe_unused]] const unsigned long long tl_loop = WXT_NOW();
+    [[maybe_unused]] unsigned long long tl_epi = 0;
+    for (;;) {                 // the workgroup's tiles: one, or (PERSIST) its share of the XCD's range
+    const int ncb = T.S.ncb, oy0 = T.oy0, ox0 = T.ox0, n0 = T.n0, f = T.f;
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
     for (int cb0 = 0; cb0 < ncb; cb0 += PP) {
 #pragma unroll
     for (int u = 0; u < PP; ++u) {
@@ -518,7 +578,9 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW,
             static_assert(PP == 1, "the interleaved schedule requests an item one iteration ahead");
             [[maybe_unused]] const unsigned long long t0 = WXT_NOW();
             const int tl = lane_id();
-            const XChunkSrc cl = x_chunk_src(S, cb + 2);
+            XChunkSrc cl;
+            if (cb + 2 >= ncb) cl = x_chunk_src(next_tile(), cb + 2 - ncb);
+            else cl = x_chunk_src(T, cb + 2);
             Mid mid[NU];
             // the group fragments of step s + 1 are requested in front of step s's MFMAs (two register sets): an LDS round trip per
             // step was a third of the MFMA steps' time (52 cycles per MFMA instead of 32 with nothing else on the SIMD)
@@ -616,42 +678,50 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW,
     }
     }
 
-    [[maybe_unused]] const unsigned long long tl_epi = WXT_NOW();
-    // ---- epilogue: two rounds of publish -> finish
+    tl_epi = WXT_NOW();
+    // ---- epilogue: NRND rounds of publish -> finish
     const int Cq = p.Cout >> 2;
     auto coff16 = [](int c8) { return (c8 >> 4) * 16 + ((c8 >> 3) & 1) * 4; };
     auto finish = [&](auto epi_c, auto act_c) __attribute__((always_inline)) {
         constexpr int EPI = decltype(epi_c)::value, ACT = decltype(act_c)::value;
         const bool has_skip = EPI == BSVD_EPI_PS_ADD && p.extra != nullptr;
+        unsigned char *const xch = xsm + C::XCH_OFF;
+        // (lane-derived values of the epilogue from an opaque copy: inside the tile loop they would otherwise be hoisted out of it and
+        //  ride through the K loop, where every register counts)
+        const int lane = lane_id();
+        const int li = lane & 31, lh = lane >> 5;
+        // finisher geometry: wave -> (block, column range); the block's channel tile -- and so the bias -- is the same in every round.
+        // The bias is requested HERE, once: a load inside a round waits (vmcnt counts loads and stores alike, in order) for the
+        // previous round's stores to be acknowledged
+        const int blk = wid % C::NBP, part = wid / C::NBP;
+        const int mtl = blk / (NH * NTW), ntg = blk % (NH * NTW);
+        const int q = lane & 3;
+        const int n8 = n0 + ntg * 32 + 8 * q;
+        f32x4 bq0 = {0.f, 0.f, 0.f, 0.f}, bq1 = bq0;
+        if (p.bias && n8 < p.Cout && part < C::NPART) {
+            bq0 = *reinterpret_cast<const f32x4 *>(p.bias + n8);
+            bq1 = *reinterpret_cast<const f32x4 *>(p.bias + n8 + 4);
+        }
 #pragma unroll
-        for (int rnd = 0; rnd < C::MT / 2; ++rnd) {
+        for (int rnd = 0; rnd < C::NRND; ++rnd) {
             if (rnd) __syncthreads();                    // round 0's readers are done
             // publish: block (mtl, channel tile hh * NTW + nt), position xi: [4 register quads][64 lanes] x 16 B, slot XOR-swizzled
 #pragma unroll
-            for (int mtl = 0; mtl < 2; ++mtl)
+            for (int mtl = 0; mtl < C::MTL; ++mtl)
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
                     const int blk = mtl * (NH * NTW) + hh * NTW + nt;
-                    unsigned char *base = xsm + (blk * A + xi) * 4096;
+                    unsigned char *base = xch + (blk * A + xi) * 4096;
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x16 &t = acc[2 * rnd + mtl][nt];
+                        const f32x16 &t = acc[C::MTL * rnd + mtl][nt];
                         const int slot = (lh * 32 + li) ^ (8 * lh + 4 * (r4 >> 1));
                         *reinterpret_cast<f32x4 *>(base + r4 * 1024 + slot * 16) = f32x4{t[4 * r4], t[4 * r4 + 1], t[4 * r4 + 2], t[4 * r4 + 3]};
                     }
                 }
             __syncthreads();
-            // finish: wave -> (block, column range)
-            const int blk = wid % C::NBP, part = wid / C::NBP;
+            // finish
             if (part >= C::NPART || (BSVD_WX_ABL & 4)) continue;
-            const int mtl = blk / (NH * NTW), ntg = blk % (NH * NTW);
-            const int q = lane & 3;
-            const int n8 = n0 + ntg * 32 + 8 * q;
-            f32x4 bq0 = {0.f, 0.f, 0.f, 0.f}, bq1 = bq0;
-            if (p.bias && n8 < p.Cout) {
-                bq0 = *reinterpret_cast<const f32x4 *>(p.bias + n8);
-                bq1 = *reinterpret_cast<const f32x4 *>(p.bias + n8 + 4);
-            }
             constexpr int JN = M / C::NPART;             // columns per finisher
             const int j0 = part * JN;
 #pragma unroll
@@ -661,7 +731,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW,
                 float mv[A][8];
 #pragma unroll
                 for (int x = 0; x < A; ++x) {
-                    const unsigned char *base = xsm + (blk * A + x) * 4096;
+                    const unsigned char *base = xch + (blk * A + x) * 4096;
                     const int slot = ((q & 1) * 32 + m) ^ (8 * (q & 1) + 4 * (q >> 1));
                     const f32x4 v0 = *reinterpret_cast<const f32x4 *>(base + (2 * (q >> 1)) * 1024 + slot * 16);
                     const f32x4 v1 = *reinterpret_cast<const f32x4 *>(base + (2 * (q >> 1) + 1) * 1024 + slot * 16);
@@ -678,7 +748,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW,
 #pragma unroll
                     for (int j = 0; j < M; ++j) ov[j][k] = oo[j];
                 }
-                const int oy = oy0 + 4 * (2 * rnd + mtl) + (m >> 3);
+                const int oy = oy0 + 4 * (C::MTL * rnd + mtl) + (m >> 3);
 #pragma unroll
                 for (int jj = 0; jj < JN; ++jj) {
                     // (compile-time column index per part keeps ov[] in registers)
@@ -736,22 +806,28 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT>::NTHREADS), (XCfg<M, NH, NTW,
         else if (p.act == BSVD_ACT_RELU) finish(integral_constant<int, BSVD_EPI_PLAIN>{}, integral_constant<int, BSVD_ACT_RELU>{});
         else finish(integral_constant<int, BSVD_EPI_PLAIN>{}, integral_constant<int, BSVD_ACT_NONE>{});
     }
+    if constexpr (!PERSIST) break;
+    jt += xcd_wgs;
+    if (jt >= xcd_count) break;
+    rot_base += ncb;
+    T = decode_tile(jt);       // (its first chunk is in V buffer 0, its chunks 1 .. PP in the raw registers, its first weight slabs in `bring`)
+    }
 #ifdef BSVD_WX_TL
     if (lane == 0 && blockIdx.x < BSVD_WX_TL_SLOTS) {
         const unsigned long long t_end = WXT_NOW();
         unsigned long long *o = g_wx_tl[blockIdx.x][wid];
         o[0] = tl_acc[0]; o[1] = tl_acc[1]; o[2] = tl_acc[2]; o[3] = tl_acc[3];
-        o[4] = tl_loop - tl_start; o[5] = t_end - tl_epi; o[6] = t_end - tl_start; o[7] = (unsigned long long)ncb;
+        o[4] = tl_loop - tl_start; o[5] = t_end - tl_epi; o[6] = t_end - tl_start; o[7] = (unsigned long long)T.S.ncb;
     }
 #endif
 }
 
-template <int M, int NH, int NTW, int MT = 4>
-static int launch_winox_cfg(const ConvParams &pin, hipStream_t stream, char *name, int name_len)
+template <int M, int NH, int NTW, int MT = 4, bool PERSIST = false>
+static int launch_winox_cfg(const ConvParams &pin, hipStream_t stream, char *name, int name_len, int max_wgs = BSVD_CUS)
 {
-    using C = XCfg<M, NH, NTW, MT>;
+    using C = XCfg<M, NH, NTW, MT, PERSIST>;
     if (name) {
-        snprintf(name, name_len, "winox_kernel<F(%d,3),%dx%d>[f16x3]%s", M, NH, NTW, MT == 2 ? "[8 rows]" : "");
+        snprintf(name, name_len, "winox_kernel<F(%d,3),%dx%d>[f16x3]%s%s", M, NH, NTW, MT == 2 ? "[8 rows]" : "", PERSIST ? "[persistent]" : "");
         return 0;
     }
     ConvParams p = pin;
@@ -761,9 +837,10 @@ static int launch_winox_cfg(const ConvParams &pin, hipStream_t stream, char *nam
     const int64_t nblk = (int64_t)p.frames * p.nty * p.ntx * p.nct;
     if (nblk <= 0 || nblk > 0x7fffffff) { set_error("bsvd_conv3x3: grid of %lld workgroups", (long long)nblk); return -1; }
     static std::atomic<int> granted[MAX_DEVICES];
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&winox_kernel<M, NH, NTW, MT>), C::LDS_BYTES, granted);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&winox_kernel<M, NH, NTW, MT, PERSIST>), C::LDS_BYTES, granted);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((winox_kernel<M, NH, NTW, MT>), dim3((unsigned)nblk), dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
+    const unsigned grid = PERSIST && nblk > max_wgs ? (unsigned)max_wgs : (unsigned)nblk;
+    hipLaunchKernelGGL((winox_kernel<M, NH, NTW, MT, PERSIST>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -772,18 +849,24 @@ int launch_winox(const ConvParams &p, hipStream_t stream, char *name, int name_l
     switch (p.wino_m) {
     case 22: return launch_winox_cfg<2, 1, 2>(p, stream, name, name_len);     // 4-wave workgroups, two per CU
     case 32: return launch_winox_cfg<2, 2, 2, 2>(p, stream, name, name_len);  // the half-height tile whatever the grid (tests, A/B)
-    case 42: return launch_winox_cfg<2, 2, 2>(p, stream, name, name_len);     // the full tile whatever the grid: launches that share the chip with
-                                                                              // another graph branch (the lagged two-chain stream step) -- idle CUs are not idle there
-    case 2: {
+    case 52: return launch_winox_cfg<2, 2, 2>(p, stream, name, name_len);     // one tile per workgroup whatever the grid (A/B of the persistent form)
+    case 62: return launch_winox_cfg<2, 2, 2, 4, true>(p, stream, name, name_len, 8);    // tests: 8 persistent workgroups walk the whole tile list
+    case 2:
+    case 42: {                // 42: never the half-height tile -- launches that share the chip with another graph branch (the lagged two-chain
+                              // stream step): idle CUs are not idle there
         // Small grids (single-frame launches of the stream schedules): one 8-wave workgroup per CU, so the launch takes
         // ceil(workgroups / 256) rounds -- 270 workgroups (256 -> 256 at 135 x 240) cost two full rounds for 1.05 rounds of work.
         // The half-height tile has twice the workgroups and computes every output with the same instruction sequence (bit-identical:
         // stream == clip stays bitwise), at ~0.87 of the full tile's efficiency (10 patch rows per 8, prologue / epilogue per tile).
+        // Large grids: 256 persistent workgroups, each walking its share of the tiles with the transform pipeline running across tile
+        // boundaries (a tile's prologue -- first loads, first transform, 10 of its 70-120 thousand cycles -- hides under its
+        // predecessor's last MFMA steps).  Same instruction sequence per output again.
         using C4 = XCfg<2, 2, 2, 4>;
         const int64_t per_row = (int64_t)p.frames * ((p.Wo + C4::TWPX - 1) / C4::TWPX) * ((p.Cout + C4::BN - 1) / C4::BN);
         const int64_t n4 = per_row * ((p.Ho + 15) / 16), n2 = per_row * ((p.Ho + 7) / 8);
         auto fill = [](int64_t n) { return (double)n / (double)(((n + BSVD_CUS - 1) / BSVD_CUS) * BSVD_CUS); };
-        if (n4 < 8 * BSVD_CUS && 0.87 * fill(n2) > fill(n4)) return launch_winox_cfg<2, 2, 2, 2>(p, stream, name, name_len);
+        if (p.wino_m == 2 && n4 < 8 * BSVD_CUS && 0.87 * fill(n2) > fill(n4)) return launch_winox_cfg<2, 2, 2, 2>(p, stream, name, name_len);
+        if (n4 >= BSVD_WX_PERSIST_MIN * BSVD_CUS) return launch_winox_cfg<2, 2, 2, 4, true>(p, stream, name, name_len);
         return launch_winox_cfg<2, 2, 2>(p, stream, name, name_len);
     }
     case 4: return launch_winox_cfg<4, 2, 1>(p, stream, name, name_len);

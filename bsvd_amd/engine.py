@@ -35,7 +35,7 @@ def head_fusable(inc0, inc3, precision):
             and not inc3.tsm and inc3.epilogue == EPI_PLAIN and inc0.act == inc3.act)
 
 
-WIDE_CONV = ("direct", "wino2", "wino4", "wino6", "wino2b", "wino4b", "wino2s", "wino2h")
+WIDE_CONV = ("direct", "wino2", "wino4", "wino6", "wino2b", "wino4b", "wino2s", "wino2h", "wino2p", "wino2n")
 
 
 WINO_MIN_CIN = 128     # narrowest layer the Winograd form takes (engine.PackedNet(wino_min_cin=...))
@@ -62,8 +62,8 @@ class PackedNet:
         self.precision = precision
         self.wide_conv = wide_conv
         # F(m,3) form; the ABI's wino_m + 10 selects the all-positions-per-wave kernel (conv3x3_wino.hip, measurement variant)
-        self.wino_m = {"direct": 0, "wino2": 2, "wino4": 4, "wino6": 6, "wino2b": 2, "wino4b": 4, "wino2s": 2, "wino2h": 2}[wide_conv]
-        self.wino_abi = self.wino_m + (10 if wide_conv.endswith("b") else 20 if wide_conv.endswith("s") else 30 if wide_conv.endswith("h") else 0)
+        self.wino_m = {"direct": 0, "wino2": 2, "wino4": 4, "wino6": 6, "wino2b": 2, "wino4b": 4, "wino2s": 2, "wino2h": 2, "wino2p": 2, "wino2n": 2}[wide_conv]
+        self.wino_abi = self.wino_m + (10 if wide_conv.endswith("b") else 20 if wide_conv.endswith("s") else 30 if wide_conv.endswith("h") else 60 if wide_conv.endswith("p") else 50 if wide_conv.endswith("n") else 0)
         self.wino_min_cin = int(os.environ.get("BSVD_WINO_MIN_CIN", WINO_MIN_CIN)) if wino_min_cin is None else int(wino_min_cin)
         self.wino = {}               # {spec.key: transformed pack} of the layers that run on the Winograd kernel
         self.tensors = {}
