@@ -309,7 +309,10 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
     //      and an inactive lane starts from the out-of-range sentinel; only columns are compared.
     MixConst mixk = {1.0f, -1.0f};
     asm volatile("" : "+s"(mixk.one), "+s"(mixk.mone));         // opaque: see dec_pair / split_pair
-    constexpr int CH = C::NTHREADS == 512 ? 2 : 4;
+#ifndef BSVD_WX_CH512
+#define BSVD_WX_CH512 2    // channels per transform item of the 512-thread workgroups (2: 4-byte loads, two items per lane; 4: 8-byte loads, one)
+#endif
+    constexpr int CH = C::NTHREADS == 512 ? (M == 2 ? BSVD_WX_CH512 : 2) : 4;
     constexpr int NDW = CH / 2;                                   // dwords per pixel and part
     struct Raw { unsigned h[A][NDW], l[A][NDW]; };
 #ifndef BSVD_WX_EMAP
@@ -424,9 +427,12 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
     // wave's extra item held the chunk barrier up for ~2000 cycles of 7900)
     // The half-height tile (10 patch rows): one full item per lane instead of two, the same left-over blocks (rows 8, 9).
     constexpr bool BAL = BSVD_WX_ILV == 2 && C::NTHREADS != 768;
-    constexpr int NFULL = C::MT == 4 ? 2 : 1;                                                 // whole-workgroup item sweeps per chunk
-    constexpr int NMAIN = C::NTHREADS == 768 ? 1 : BAL ? NFULL + 1 : NFULL;
-    constexpr int NROT = (C::NTHREADS == 768 || BAL) ? 0 : C::NTHREADS == 512 ? 2 : 1;      // 64-item blocks left over per chunk
+    constexpr int NITEMS = C::PR * (CH == 4 ? 32 : 64);
+    constexpr int NFULL = NITEMS / C::NTHREADS;                                               // whole-workgroup item sweeps per chunk
+    constexpr int REM = NITEMS - NFULL * C::NTHREADS;
+    constexpr bool PARTIAL = C::NTHREADS != 768 && (REM % 64 != 0 || NFULL == 0);             // the rest as one more sweep with the lanes beyond it idle
+    constexpr int NMAIN = C::NTHREADS == 768 ? 1 : (BAL || PARTIAL) ? NFULL + 1 : NFULL;
+    constexpr int NROT = (C::NTHREADS == 768 || BAL || PARTIAL) ? 0 : REM / 64;               // 64-item blocks left over per chunk
     constexpr int ROT0 = NFULL * C::NTHREADS;                                                 // first left-over item
     static_assert(C::NTHREADS == 768 || C::NTHREADS == 512 || C::NTHREADS == 256, "item map");
     auto lane_id = [&]() __attribute__((always_inline)) {      // opaque per use: the item geometry is re-derived per chunk -- hoisted out of the K loop it pins ~30 registers
@@ -435,10 +441,10 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
         return tl;
     };
     auto main_E = [&](int k, int tl) __attribute__((always_inline)) {
-        return C::NTHREADS == 768 ? wid * 48 + tl : k < NFULL ? k * C::NTHREADS + wid * 64 + tl : ROT0 + wid * (64 * (C::NTHREADS == 512 ? 2 : 1) / C::NW) + tl;
+        return C::NTHREADS == 768 ? wid * 48 + tl : (k < NFULL || PARTIAL) ? k * C::NTHREADS + wid * 64 + tl : ROT0 + wid * (REM / C::NW) + tl;
     };
     auto main_active = [&](int k, int tl) __attribute__((always_inline)) {
-        return C::NTHREADS == 768 ? tl < 48 : k < NFULL ? true : tl < 64 * (C::NTHREADS == 512 ? 2 : 1) / C::NW;
+        return C::NTHREADS == 768 ? tl < 48 : k < NFULL ? true : PARTIAL ? k * C::NTHREADS + wid * 64 + tl < NITEMS : tl < REM / C::NW;
     };
     int rot_base = 0;          // chunks of the workgroup's earlier tiles: the rotation runs on across tiles (a chunk is requested under one tile's
                                // numbering and finished under the next one's)
@@ -452,7 +458,10 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
 #ifndef BSVD_WX_PP_PERSIST
 #define BSVD_WX_PP_PERSIST 1   // raw register sets of the persistent form
 #endif
-    constexpr int PP = (M == 2 && C::NTHREADS == 512 && BSVD_WX_ILV != 2) ? (PERSIST ? BSVD_WX_PP_PERSIST : 2) : 1;
+#ifndef BSVD_WX_PP
+#define BSVD_WX_PP 2       // raw register sets of F(2,3)'s 512-thread workgroups
+#endif
+    constexpr int PP = (M == 2 && C::NTHREADS == 512 && BSVD_WX_ILV != 2) ? (PERSIST ? BSVD_WX_PP_PERSIST : BSVD_WX_PP) : 1;
     Raw raw[PP][NMAIN], raw_rot[PP];
     using PAll = std::integral_constant<int, 3>;     // part_: 1 the lanes' main items, 2 the rotating left-over block, 3 both
     auto chunk_load = [&](int cc, int SET, auto part_, int tl) __attribute__((always_inline)) {
