@@ -859,7 +859,11 @@ int launch_winox(const ConvParams &p, hipStream_t stream, char *name, int name_l
     case 22: return launch_winox_cfg<2, 1, 2>(p, stream, name, name_len);     // 4-wave workgroups, two per CU
     case 32: return launch_winox_cfg<2, 2, 2, 2>(p, stream, name, name_len);  // the half-height tile whatever the grid (tests, A/B)
     case 52: return launch_winox_cfg<2, 2, 2>(p, stream, name, name_len);     // one tile per workgroup whatever the grid (A/B of the persistent form)
-    case 62: return launch_winox_cfg<2, 2, 2, 4, true>(p, stream, name, name_len, 8);    // tests: 8 persistent workgroups walk the whole tile list
+    case 62: {               // the persistent form whatever the grid (tests, records): small grids on 8 workgroups, so that every one walks several tiles
+        using C4 = XCfg<2, 2, 2, 4>;
+        const int64_t n4 = (int64_t)p.frames * ((p.Wo + C4::TWPX - 1) / C4::TWPX) * ((p.Cout + C4::BN - 1) / C4::BN) * ((p.Ho + 15) / 16);
+        return launch_winox_cfg<2, 2, 2, 4, true>(p, stream, name, name_len, n4 < 2 * BSVD_CUS ? 8 : BSVD_CUS);
+    }
     case 2:
     case 42: {                // 42: never the half-height tile -- launches that share the chip with another graph branch (the lagged two-chain
                               // stream step): idle CUs are not idle there

@@ -1,7 +1,9 @@
 #!/bin/bash
 # The Winograd kernel's measurement record in one GPU-box session (profiles/<tag>_wino_*).
 # Needs the variant libraries of
-#   tools/build_ab.sh "" "-DBSVD_WX_ABL=1" "-DBSVD_WX_ABL=2" "-DBSVD_WX_ABL=3" "-DBSVD_WX_ABL=4" "-DBSVD_WX_ABL=8" "-DBSVD_WX_ABL=16" "-DBSVD_WX_ABL=32" "-DBSVD_WX_TL"
+#   tools/build_ab.sh "" "-DBSVD_WX_ABL=1" "-DBSVD_WX_ABL=2" "-DBSVD_WX_ABL=3" "-DBSVD_WX_ABL=4" "-DBSVD_WX_ABL=8" "-DBSVD_WX_ABL=64" "-DBSVD_WX_EMAP=0 -DBSVD_WX_XIN=0" "-DBSVD_WX_TL"
+# (ab0 shipped; 1 no transform; 2 no MFMA steps; 3 neither; 4 no epilogue finish; 8 no chunk barrier; 64 no activation loads in the K loop;
+#  ab7 the round's first load path: quarter-major items, compare / select per position; ab8 timeline)
 # usage on the GPU box: tools/wino_records.sh <tag>
 TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
@@ -9,7 +11,7 @@ O=$R/gpurun_out
 cd $R
 f() { grep -v amdgpu.ids; }
 # 1. every form, layer by layer, on the same realistic input (sustained loops: the power cap applies)
-python tools/debug/wino_layer_bench.py 2 direct,wino2,wino2h,wino2s,wino4,wino6,wino2b 2>&1 | f > $O/${TAG}_wino_layers.txt
+python tools/debug/wino_layer_bench.py 2 direct,wino2,wino2h,wino2s,wino2p,wino4,wino6,wino2b 2>&1 | f > $O/${TAG}_wino_layers.txt
 # 2. timing-only ablations of the shipped F(2,3) kernel and of F(6,3) (results wrong by construction)
 { cat build/ab/variants.txt
   for i in 0 1 2 3 4 5 6 7; do
@@ -17,7 +19,7 @@ python tools/debug/wino_layer_bench.py 2 direct,wino2,wino2h,wino2s,wino4,wino6,
     BSVD_HIP_LIB=$R/build/ab/lib_ab$i.so WINO_LAYERS=0,1 python tools/debug/wino_layer_bench.py 1 wino2,wino6 2>&1 | f | grep -v BSVD_HIP_LIB | cut -c1-110
   done; } > $O/${TAG}_wino_ablation.txt
 # 3. per-section cycle split (timeline build)
-{ for a in "wino2 256 256 135 240 10" "wino2 128 128 270 480 10" "wino6 256 256 135 240 10" "wino2h 256 256 135 240 1"; do
+{ for a in "wino2 256 256 135 240 10" "wino2 128 128 270 480 10" "wino6 256 256 135 240 10" "wino2h 256 256 135 240 1" "wino2p 256 256 135 240 10"; do
     BSVD_HIP_LIB=$R/build/ab/lib_ab8.so python tools/debug/wx_timeline.py $a 2>&1 | f | grep -v BSVD_HIP_LIB
   done; } > $O/${TAG}_wino_timeline.txt
 # 4. MFMA / VALU co-issue microbenchmark
