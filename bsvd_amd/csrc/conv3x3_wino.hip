@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const ConvParams p)
 const char *wino_unsupported(const ConvParams &p, int stride)
 {
     if (p.prec != 1) return "dtype must be BSVD_F16X3";
-    if (p.wino_m != 2 && p.wino_m != 4 && p.wino_m != 6 && p.wino_m != 12 && p.wino_m != 14 && p.wino_m != 22 && p.wino_m != 32 && p.wino_m != 42 && p.wino_m != 52 && p.wino_m != 62) return "wino_m must be 2, 4 or 6 (12 | 14: the all-positions-per-wave kernel; 22 | 32 | 42: F(2,3) on 4-wave workgroups / always on the half-height tile / never on it)";
+    if (p.wino_m != 2 && p.wino_m != 4 && p.wino_m != 6 && p.wino_m != 12 && p.wino_m != 14 && p.wino_m != 22 && p.wino_m != 32 && p.wino_m != 42 && p.wino_m != 52 && p.wino_m != 62 && p.wino_m != 36 && p.wino_m != 46) return "wino_m must be 2, 4 or 6 (12 | 14: the all-positions-per-wave kernel; 22 | 32 | 42: F(2,3) on 4-wave workgroups / always on the half-height tile / never on it)";
     if (stride != 1) return "stride must be 1";
     if (p.epilogue == BSVD_EPI_RESID || p.y_planar_ch > 0 || p.head_w) return "only PLAIN / PS_ADD NHWC layers";
     if ((p.fold & 15) != 0) return "fold must be a multiple of 16";

@@ -883,7 +883,16 @@ int launch_winox(const ConvParams &p, hipStream_t stream, char *name, int name_l
         return launch_winox_cfg<2, 2, 2>(p, stream, name, name_len);
     }
     case 4: return launch_winox_cfg<4, 2, 1>(p, stream, name, name_len);
-    default: return launch_winox_cfg<6, 1, 2>(p, stream, name, name_len);
+    case 36: return launch_winox_cfg<6, 1, 2, 2>(p, stream, name, name_len);   // F(6,3) on the half-height tile whatever the grid (tests, A/B)
+    case 46: return launch_winox_cfg<6, 1, 2>(p, stream, name, name_len);      // ... never on it (launches that share the chip, see 42)
+    default: {                // F(6,3): the same choice between the 16- and the 8-row tile for grids that do not fill the chip
+        using C4 = XCfg<6, 1, 2, 4>;
+        const int64_t per_row = (int64_t)p.frames * ((p.Wo + C4::TWPX - 1) / C4::TWPX) * ((p.Cout + C4::BN - 1) / C4::BN);
+        const int64_t n4 = per_row * ((p.Ho + 15) / 16), n2 = per_row * ((p.Ho + 7) / 8);
+        auto fill = [](int64_t n) { return (double)n / (double)(((n + BSVD_CUS - 1) / BSVD_CUS) * BSVD_CUS); };
+        if (n4 < 8 * BSVD_CUS && 0.87 * fill(n2) > fill(n4)) return launch_winox_cfg<6, 1, 2, 2>(p, stream, name, name_len);
+        return launch_winox_cfg<6, 1, 2>(p, stream, name, name_len);
+    }
     }
 }
 

@@ -35,7 +35,7 @@ def head_fusable(inc0, inc3, precision):
             and not inc3.tsm and inc3.epilogue == EPI_PLAIN and inc0.act == inc3.act)
 
 
-WIDE_CONV = ("direct", "wino2", "wino4", "wino6", "wino2b", "wino4b", "wino2s", "wino2h", "wino2p", "wino2n")
+WIDE_CONV = ("direct", "wino2", "wino4", "wino6", "wino2b", "wino4b", "wino2s", "wino2h", "wino2p", "wino2n", "wino6h", "wino26")
 
 
 WINO_MIN_CIN = 128     # narrowest layer the Winograd form takes (engine.PackedNet(wino_min_cin=...))
@@ -62,10 +62,11 @@ class PackedNet:
         self.precision = precision
         self.wide_conv = wide_conv
         # F(m,3) form; the ABI's wino_m + 10 selects the all-positions-per-wave kernel (conv3x3_wino.hip, measurement variant)
-        self.wino_m = {"direct": 0, "wino2": 2, "wino4": 4, "wino6": 6, "wino2b": 2, "wino4b": 4, "wino2s": 2, "wino2h": 2, "wino2p": 2, "wino2n": 2}[wide_conv]
+        self.wino_m = {"direct": 0, "wino2": 2, "wino4": 4, "wino6": 6, "wino2b": 2, "wino4b": 4, "wino2s": 2, "wino2h": 2, "wino2p": 2, "wino2n": 2, "wino6h": 6, "wino26": 6}[wide_conv]
         self.wino_abi = self.wino_m + (10 if wide_conv.endswith("b") else 20 if wide_conv.endswith("s") else 30 if wide_conv.endswith("h") else 60 if wide_conv.endswith("p") else 50 if wide_conv.endswith("n") else 0)
         self.wino_min_cin = int(os.environ.get("BSVD_WINO_MIN_CIN", WINO_MIN_CIN)) if wino_min_cin is None else int(wino_min_cin)
         self.wino = {}               # {spec.key: transformed pack} of the layers that run on the Winograd kernel
+        self.wino_layer_abi = {}     # {spec.key: BsvdConvArgs.wino_m} -- "wino26": F(2,3) for the 128 -> 128 layers, F(6,3) for the wider ones
         self.tensors = {}
         self.order = {sp.key: i for i, sp in enumerate(net.layers)}      # position in the layer-major walk (tile_order parity)
         edge = set()
@@ -83,13 +84,18 @@ class PackedNet:
                     raise ValueError("%s.weight has shape %s, expected %s" % (sp.key, tuple(w.shape), (sp.cout, sp.cin, 3, 3)))
                 bp = torch.empty(sp.cout_pad, dtype=torch.float32, device=device)
                 if self.wino_m and wino_eligible(sp, precision, self.wino_min_cin):
-                    n = lib.bsvd_packed_wino_weight_elems(sp.cin_pad, sp.cout_pad, self.wino_m)
+                    # (a property of the LAYER, like eligibility itself: every schedule runs the same form per layer)
+                    m, abi = self.wino_m, self.wino_abi
+                    if wide_conv == "wino26" and sp.cin_pad <= 128 and sp.cout_pad <= 128:
+                        m = abi = 2
+                    n = lib.bsvd_packed_wino_weight_elems(sp.cin_pad, sp.cout_pad, m)
                     wq = torch.empty(n, dtype=torch.float32, device=device)
                     rc = lib.bsvd_pack_weights_wino(w.data_ptr(), b.data_ptr() if b is not None else None, sp.cin, sp.cout,
-                                                    sp.cin_pad, sp.cout_pad, 1 if sp.epilogue == EPI_PS_ADD else 0, self.wino_m,
+                                                    sp.cin_pad, sp.cout_pad, 1 if sp.epilogue == EPI_PS_ADD else 0, m,
                                                     wq.data_ptr(), bp.data_ptr(), _stream_ptr())
                     _lib.check(rc, "bsvd_pack_weights_wino(%s)" % sp.key)
                     self.wino[sp.key] = wq
+                    self.wino_layer_abi[sp.key] = abi
                     self.tensors[sp.key] = (None, bp)
                     continue
                 n = lib.bsvd_packed_weight_elems(sp.cin_pad, sp.cout_pad)
@@ -298,9 +304,9 @@ class HipExecutor:
         if wp is not None:
             a.w_packed = wp.data_ptr()
         else:
-            a.w_wino_packed, a.wino_m = self.packed.wino[sp.key].data_ptr(), self.packed.wino_abi
-            if self.wino_full_tile and a.wino_m == 2:
-                a.wino_m = 42         # this launch shares the chip with another graph branch: never the half-height tile (same bits)
+            a.w_wino_packed, a.wino_m = self.packed.wino[sp.key].data_ptr(), self.packed.wino_layer_abi[sp.key]
+            if self.wino_full_tile and a.wino_m in (2, 6):
+                a.wino_m += 40        # this launch shares the chip with another graph branch: never the half-height tile (same bits)
         if extra is not None:
             a.extra = extra.data_ptr()
             a.extra_frame_stride = extra[0].numel()

@@ -236,7 +236,7 @@ class StreamEngine:
         rec = recorder.take()
         sig = _signature(rec)
         pk = getattr(self.ex, "packed", None)
-        shared_chip = bool(shared_chip and self.hip and pk is not None and getattr(pk, "wino", None) and pk.wino_abi == 2)
+        shared_chip = bool(shared_chip and self.hip and pk is not None and getattr(pk, "wino", None) and any(v in (2, 6) for v in pk.wino_layer_abi.values()))
         if shared_chip:             # (only an engine whose launches pick their own tile keeps two sets of plans)
             sig = ("shared", sig)
         plan = self.plans.get(sig)

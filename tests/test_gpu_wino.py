@@ -36,7 +36,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("wide_conv", ["wino2", "wino4", "wino6", "wino2b", "wino2s", "wino2h", "wino2p"])
+@pytest.mark.parametrize("wide_conv", ["wino2", "wino4", "wino6", "wino2b", "wino2s", "wino2h", "wino2p", "wino6h"])
 @pytest.mark.parametrize("cin,cout,tsm,act,epi,T,H,W", CASES)
 def test_wino_layer_vs_oracle(wide_conv, cin, cout, tsm, act, epi, T, H, W):
     from bsvd_amd.netspec import ConvSpec

@@ -19,6 +19,12 @@ LAYERS = [  # cin, cout, tsm, act, epi, H, W, T
     (256, 512, False, "none", 1, 135, 240, 10),
     (128, 128, True, "relu6", 0, 270, 480, 1),
     (256, 256, True, "relu6", 0, 135, 240, 1),
+    (128, 256, False, "none", 1, 270, 480, 1),
+    (256, 512, False, "none", 1, 135, 240, 1),
+    (128, 128, True, "relu6", 0, 540, 960, 1),      # the 1080p stream (C5): single-frame launches at twice the size
+    (256, 256, True, "relu6", 0, 270, 480, 1),
+    (128, 256, False, "none", 1, 540, 960, 1),
+    (256, 512, False, "none", 1, 270, 480, 1),
 ]
 if os.environ.get("WINO_LAYERS"):
     LAYERS = [LAYERS[int(i)] for i in os.environ["WINO_LAYERS"].split(",")]
