@@ -50,8 +50,11 @@ def remove_registration_hooks():
     while _HOOK_HANDLES:
         _HOOK_HANDLES.pop().remove()
 
-# Arithmetic form of the wide stride-1 layers in the split mode (engine.wino_eligible): 'direct' (3-pass implicit GEMM),
-# 'wino2' / 'wino4' (1-D Winograd F(2,3) / F(4,3) along x, conv3x3_wino.hip).  wide_conv='auto' takes BSVD_WIDE_CONV or this.
+# Arithmetic form of the wide stride-1 layers in the split mode (engine.wino_eligible): 'direct' (3-pass implicit GEMM), 'wino2' / 'wino4' /
+# 'wino6' (1-D Winograd F(2,3) / F(4,3) / F(6,3) along x, conv3x3_winox.hip), 'wino26' (F(2,3) on the 128 -> 128 layers, F(6,3) on the wider
+# ones); the other members of engine.WIDE_CONV are measurement / test variants.  wide_conv='auto' takes BSVD_WIDE_CONV or this.
+# F(2,3) gains in every schedule (clip +4 %, per-frame stream +5 % over 'direct'); F(6,3) is 1-4 % faster on clips and 6 % slower per
+# frame at 540 x 960.  One form per model: clip, stream and sharded schedules stay bit-identical to each other.
 WIDE_CONV_DEFAULT = "wino2"
 F16X3_WEIGHT_LIMIT = 6.0e4      # |folded weight| beyond this cannot be carried as an fp16 pair (fp16 max 65504)
 
