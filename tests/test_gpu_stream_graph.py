@@ -38,6 +38,29 @@ def test_ring_graph_stream_equals_clip_bitwise(precision):
     assert st["graph_captures"] > 0 and st["graph_replays"] > st["graph_captures"]
 
 
+@pytest.mark.parametrize("wide_conv", ["direct", "wino2", "wino6", "wino26", "wino4"])
+def test_every_form_of_the_wide_layers_streams_bit_identically_and_stays_in_the_error_class(wide_conv):
+    """BSVD(wide_conv=...): the arithmetic form of the wide layers is a property of the model, so the reference's two call protocols
+    (bsvd_arch.py:485-552 clip loop, :555-569 per-frame feed) agree bit for bit in every form -- also where a launch picks another tile
+    of the same form (single frames: the 8-row tile; the lagged two-branch step: the full tile) -- and every form is as close to the
+    exact-fp32 mode as the direct split kernel (same weights, same clip)."""
+    m = _model("f16x3", wide_conv=wide_conv)
+    ref = _model("fp32")
+    ref.load_state_dict(m.state_dict())
+    assert m._executor(torch.device("cuda", 0)).packed.wide_conv == wide_conv
+    for F, H, W in ((5, 48, 80), (19, 144, 256)):          # the second: 256-channel single-frame launches on more than one tile row
+        x = torch.rand(F, 4, H, W, device="cuda:0")
+        want = m.clip_forward(x)
+        err = float((want - ref.clip_forward(x)).abs().max())
+        print("%s %dx%dx%d: max-abs vs exact fp32 %.2e" % (wide_conv, F, H, W, err))
+        assert err < 3e-4
+        for rep in range(2):
+            assert torch.equal(_per_frame(m, x), want), (F, rep)
+            for chunk in (1, "auto"):
+                m.stream_chunk = chunk
+                assert torch.equal(m.streaming_forward(x), want), (F, rep, chunk)
+
+
 def test_graph_path_equals_allocating_stream_path_and_no_graph_path():
     x = torch.rand(29, 4, 48, 64, device="cuda:0")
     a = _model("f16x3", stream_rings=False, stream_overlap=False)
