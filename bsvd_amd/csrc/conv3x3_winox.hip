@@ -378,7 +378,10 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
                 float d[A];
-                if constexpr (BSVD_WX_ILV != 1) __builtin_amdgcn_sched_barrier(0);    // one channel at a time (the scheduler otherwise decodes everything first: 64 live floats at M = 6)
+#ifndef BSVD_WX_CHBAR
+#define BSVD_WX_CHBAR 1    // scheduling fence per channel of an item (0: the scheduler may interleave an item's channels: more ILP, more live floats)
+#endif
+                if constexpr (BSVD_WX_ILV != 1 && (BSVD_WX_CHBAR || M != 2)) __builtin_amdgcn_sched_barrier(0);    // one channel at a time (the scheduler otherwise decodes everything first: 64 live floats at M = 6)
 #pragma unroll
                 for (int i = 0; i < A; ++i) d[i] = cc ? dec_pair<1>(r.h[i][cp], r.l[i][cp], mixk) : dec_pair<0>(r.h[i][cp], r.l[i][cp], mixk);
                 F::input(d, v[cc]);

@@ -119,7 +119,9 @@ typedef struct BsvdConvArgs {
      * all-positions-per-wave variant conv3x3_wino.hip on the same F(2,3) / F(4,3) pack, 22 / 32 force F(2,3)'s 4-wave workgroup /
      * its half-height tile -- kept for measurements and tests; wino_m = 2 picks the half-height tile itself for grids that
      * do not fill the chip, bit-identical to the full tile, and 42 = F(2,3) always on the full tile is for launches that run
-     * beside another stream's or graph branch's kernels) with the
+     * beside another stream's or graph branch's kernels; 36 / 46 are the same two for F(6,3), which picks its tile like F(2,3);
+     * 52 / 62 = F(2,3) one tile per workgroup / as persistent workgroups, whatever the grid: the persistent form is slower and
+     * never chosen by wino_m = 2) with the
      * TRANSFORMED weights of bsvd_pack_weights_wino(); w_packed is then
      * ignored (may be NULL).  Same contract and tensors as the direct form -- gather, halos, bias, activation, PLAIN / PS_ADD
      * epilogues -- but 6 (F(2,3)), 4.5 (F(4,3)) or 4 (F(6,3)) instead of 9 tap-GEMMs per output pixel; results differ from the direct
