@@ -45,6 +45,24 @@ def test_random_layer_split_fp16(seed):
     S.test_layer_split_vs_oracle(*args)
 
 
+@pytest.mark.parametrize("seed", range(36))
+def test_random_wide_layer_winograd_forms(seed):
+    """The Winograd kernels on random eligible layers (stride 1, 128 / 256 input channels; bsvd_arch.py:21-50, :257-267): ragged sizes in
+    both directions, 1 to 3 frames, every halo form of the temporal gather, PixelShuffle + skip, the three activations; every kernel variant
+    in turn (F(2,3) / F(4,3) / F(6,3), their 8-row tiles, the 4-wave and the persistent F(2,3))."""
+    import test_gpu_wino as WN
+    rs = np.random.RandomState(7000 + seed)
+    form = ["wino2", "wino6", "wino2h", "wino4", "wino6h", "wino2p", "wino2s"][seed % 7]
+    epi = int(rs.choice([0, 0, 1]))
+    tsm = bool(epi == 0 and rs.rand() < 0.6)
+    cin = int(rs.choice([128, 256]))
+    cout = cin if tsm else int(rs.choice([128, 256, 512] if epi == 1 else [64, 128, 256]))
+    act = str(rs.choice(["relu6", "relu", "none"])) if epi == 0 else "none"
+    T, H, W = int(rs.randint(1, 4)), int(rs.randint(1, 21)), int(rs.randint(1, 49))
+    print("case", form, cin, cout, tsm, act, epi, T, H, W)
+    WN.test_wino_layer_vs_oracle(form, cin, cout, tsm, act, epi, T, H, W)
+
+
 @pytest.mark.parametrize("seed", range(15))
 def test_random_clip_whole_network(seed):
     """bsvd_c64 on random small clips (any T >= 1, H and W multiples of 4 from 4 to 48): clip schedule vs the CPU oracle
