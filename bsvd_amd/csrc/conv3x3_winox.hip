@@ -91,7 +91,13 @@ struct XCfg {
     static constexpr int TR = 4 * MT, TWPX = 8 * M;   // pixel tile: 16 (8) rows x 8 M columns
     static constexpr int PR = TR + 2;             // patch rows
     static constexpr int NSLOT = PR * 8;
-    static constexpr int PLANE = NSLOT * 16;      // bytes of one (xi, quarter) plane
+#ifndef BSVD_WX_PLANE_PAD
+#define BSVD_WX_PLANE_PAD 0     // bytes added to a plane.  NSLOT * 16 is a multiple of 256 B (all 64 banks), so the two quarters an item wave stores at
+                                // once -- adjacent lanes since the item order puts a pixel's quarters side by side -- meet in the same banks: PMC 0.19
+                                // of the LDS-active cycles are conflict cycles.  128 removes them and changes nothing (-0.5 %): as on the direct
+                                // tiles in round 3, LDS conflicts are not what this kernel waits for
+#endif
+    static constexpr int PLANE = NSLOT * 16 + BSVD_WX_PLANE_PAD;      // bytes of one (xi, quarter) plane
     static constexpr int V_BUF = A * 4 * PLANE;
     static constexpr int NITEM = NSLOT * 4;       // transform items (row, group, 4 channels) per chunk: 576
     static constexpr int BN = NH * NTW * 32;      // output channels per workgroup
