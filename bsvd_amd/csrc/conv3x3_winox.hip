@@ -436,6 +436,16 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
     // wave's extra item held the chunk barrier up for ~2000 cycles of 7900)
     // The half-height tile (10 patch rows): one full item per lane instead of two, the same left-over blocks (rows 8, 9).
     constexpr bool BAL = BSVD_WX_ILV == 2 && C::NTHREADS != 768;
+#ifndef BSVD_WX_DEADROWS
+#define BSVD_WX_DEADROWS 0     // 1: a tile with <= 8 image rows (the last tile row of a 135- or 120-row layer) runs its two upper MFMA tiles only: half the MFMA
+                               // steps, the transform of patch rows 0 .. 9 only, one epilogue round; bit-identical.  Measured: 256 -> 256 at 135 rows -1.7 %,
+                               // 256 -> 512 =, and 128 -> 128 at 270 rows (no such tile) +1.7 % -- the six wave-uniform branches split the MFMA steps'
+                               // scheduling regions for every tile.  Net zero on the clip: off
+#endif
+    constexpr bool DEADROWS = BSVD_WX_DEADROWS && M == 2 && C::MT == 4 && !PERSIST && BSVD_WX_ILV == 0;    // (F(6,3): 25 spills with it)
+    bool half_live = false;        // wave uniform, set per tile
+    // first patch row of main item sweep k of this wave (a wave's 64 items of a sweep are one row, or two with 4-channel items)
+    auto sweep_dead = [&](int k) __attribute__((always_inline)) { return half_live && ((k * C::NTHREADS + wid * 64) >> (CH == 4 ? 5 : 6)) > 9; };
     constexpr int NITEMS = C::PR * (CH == 4 ? 32 : 64);
     constexpr int NFULL = NITEMS / C::NTHREADS;                                               // whole-workgroup item sweeps per chunk
     constexpr int REM = NITEMS - NFULL * C::NTHREADS;
@@ -480,21 +490,21 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
         else c = x_chunk_src(T, cc);
         if constexpr (decltype(part_)::value & 1) {
 #pragma unroll
-        for (int k = 0; k < NMAIN; ++k) item_load(c, main_E(k, tl), main_active(k, tl), raw[SET][k]);
+        for (int k = 0; k < NMAIN; ++k) if (!sweep_dead(k)) item_load(c, main_E(k, tl), main_active(k, tl), raw[SET][k]);
         }
         if constexpr (NROT > 0 && (decltype(part_)::value & 2)) {
             const int rs = rot_slot(cc);
-            if (rs >= 0) item_load(c, ROT0 + rs * 64 + tl, true, raw_rot[SET]);
+            if (rs >= 0 && !half_live) item_load(c, ROT0 + rs * 64 + tl, true, raw_rot[SET]);        // (left-over blocks: patch rows 16, 17)
         }
     };
     auto chunk_finish = [&](int cc, unsigned char *vbuf, int SET, auto part_, int tl) __attribute__((always_inline)) {
         if constexpr (decltype(part_)::value & 1) {
 #pragma unroll
-        for (int k = 0; k < NMAIN; ++k) item_finish(vbuf, main_E(k, tl), main_active(k, tl), raw[SET][k]);
+        for (int k = 0; k < NMAIN; ++k) if (!sweep_dead(k)) item_finish(vbuf, main_E(k, tl), main_active(k, tl), raw[SET][k]);
         }
         if constexpr (NROT > 0 && (decltype(part_)::value & 2)) {
             const int rs = rot_slot(cc);
-            if (rs >= 0) item_finish(vbuf, ROT0 + rs * 64 + tl, true, raw_rot[SET]);
+            if (rs >= 0 && !half_live) item_finish(vbuf, ROT0 + rs * 64 + tl, true, raw_rot[SET]);
         }
     };
 
@@ -521,6 +531,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
     [[maybe_unused]] unsigned long long tl_epi = 0;
     for (;;) {                 // the workgroup's tiles: one, or (PERSIST) its share of the XCD's range
     const int ncb = T.S.ncb, oy0 = T.oy0, ox0 = T.ox0, n0 = T.n0, f = T.f;
+    half_live = DEADROWS && p.Ho - oy0 <= 8;
 #pragma unroll
     for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
@@ -535,22 +546,26 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
         const int setv = PP == 2 ? ((u + 1) & 1) : 0;          // the raw set of chunk cb + 1 (a constant after unrolling)
         const unsigned char *pcur = xsm + (cb & 1) * C::V_BUF + a_lane;
         unsigned char *pnext = xsm + ((cb + 1) & 1) * C::V_BUF;
-        auto mfma_phase = [&]() __attribute__((always_inline)) {
+        auto mfma_phase = [&](auto nmt_) __attribute__((always_inline)) {      // NMT: the MFMA tiles (4-row bands) of the tile that hold image rows
+            constexpr int NMT = decltype(nmt_)::value;
             f32x4 afr[2][2];          // fragments one (ky, mt) step ahead, see the interleaved schedule
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) afr[0][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE);
-            static_for<0, 3 * C::MT>([&](auto k_) __attribute__((always_inline)) {
-                constexpr int S_ = decltype(k_)::value, KY = S_ / C::MT, mt = S_ % C::MT;
+            static_for<0, 3 * NMT>([&](auto k_) __attribute__((always_inline)) {
+                constexpr int S_ = decltype(k_)::value, KY = S_ / NMT, mt = S_ % NMT;
                 const f32x4 (&b)[NTW][2] = bring[KY];
                 {
-                    if constexpr (S_ < 3 * C::MT - 1) {
-                        constexpr int KY1 = (S_ + 1) / C::MT, mt1 = (S_ + 1) % C::MT;
+                    if constexpr (S_ < 3 * NMT - 1) {
+                        constexpr int KY1 = (S_ + 1) / NMT, mt1 = (S_ + 1) % NMT;
 #pragma unroll
                         for (int pt = 0; pt < 2; ++pt)
                             afr[(S_ + 1) & 1][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE + (4 * mt1 + KY1) * 128);
                     }
                     const f32x4 (&a)[2] = afr[S_ & 1];
                     __builtin_amdgcn_sched_barrier(0);
+                    // (ONE copy of the steps with the lower bands' MFMAs under a wave-uniform condition: two copies of the phase, 6 and 12 steps,
+                    //  made the allocator carry the accumulators twice and spill 840 registers)
+                    if (!(DEADROWS && mt >= 2 && half_live)) {
 #pragma unroll
                     for (int pass = 0; pass < 3; ++pass)
 #pragma unroll
@@ -560,6 +575,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
                             const f16x8 av = __builtin_bit_cast(f16x8, a[pass == 0 ? 1 : 0]);
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv, av, acc[mt][nt], 0, 0, 0);
                         }
+                    }
                 }
             });
             // the weights of the NEXT chunk, all three slabs, requested here: a wave's loads return in issue order, so every load a
@@ -661,7 +677,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
             __builtin_amdgcn_sched_barrier(0);
             // one scheduling region: MFMA steps + this lane's main items of the next chunk + the requests for the chunk after
             chunk_finish(cb + 1, pnext, setv, PMain{}, tl);
-            mfma_phase();
+            mfma_phase(std::integral_constant<int, C::MT>{});
             chunk_load(cb + 1 + PP, setv, PMain{}, tl);
             static_for<0, 3 * C::MT * 3 * NTW>([&](auto) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // one MFMA
@@ -684,7 +700,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
         if (!(BSVD_WX_ABL & 1) && phase != 0) xform();
         __builtin_amdgcn_sched_barrier(0);
         [[maybe_unused]] const unsigned long long t1 = WXT_NOW();
-        if (!(BSVD_WX_ABL & 2)) mfma_phase();
+        if (!(BSVD_WX_ABL & 2)) mfma_phase(std::integral_constant<int, C::MT>{});
         __builtin_amdgcn_sched_barrier(0);
         [[maybe_unused]] const unsigned long long t2 = WXT_NOW();
         if (!(BSVD_WX_ABL & 1) && phase == 0) xform();
@@ -722,6 +738,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
         }
 #pragma unroll
         for (int rnd = 0; rnd < C::NRND; ++rnd) {
+            if (DEADROWS && half_live && C::MTL * rnd >= 2) break;       // (wave uniform, the same for every wave of the workgroup) no image rows in this round's MFMA tiles
             if (rnd) __syncthreads();                    // round 0's readers are done
             // publish: block (mtl, channel tile hh * NTW + nt), position xi: [4 register quads][64 lanes] x 16 B, slot XOR-swizzled
 #pragma unroll
