@@ -104,10 +104,15 @@ struct XCfg {
     // epilogue exchange: per round the tiles of MTL MFMA tiles x (NH NTW) channel tiles x A positions, 4 KB each.  It aliases the V
     // buffers -- except in the persistent form, where the next tile's first chunk is already transformed when the epilogue runs:
     // there it sits behind them, and holds one MFMA tile per round so that everything fits 160 KB
-    static constexpr int MTL = PERSIST ? 1 : 2;
+#ifndef BSVD_WX_EPI2
+#define BSVD_WX_EPI2 0     // 1 (F(2,3)): the exchange as two half-size buffers, one MFMA tile per round: round r + 1 is published while round r is finished
+#endif
+    static constexpr bool EPI2 = BSVD_WX_EPI2 && M == 2 && !PERSIST;
+    static constexpr int MTL = (PERSIST || EPI2) ? 1 : 2;
     static constexpr int NRND = MT / MTL;
     static constexpr int NBP = MTL * NH * NTW;    // blocks per round
-    static constexpr int XCH_BYTES = NBP * A * 4096;
+    static constexpr int XCH_ROUND = NBP * A * 4096;
+    static constexpr int XCH_BYTES = XCH_ROUND * (EPI2 ? 2 : 1);
     static constexpr int XCH_OFF = PERSIST ? 2 * V_BUF : 0;
     static constexpr int LDS_BYTES = PERSIST ? 2 * V_BUF + XCH_BYTES : (2 * V_BUF > XCH_BYTES ? 2 * V_BUF : XCH_BYTES);
     static constexpr int NPART = NW / NBP >= 2 ? 2 : 1;          // finishers per block (column ranges)
@@ -736,17 +741,16 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
             bq0 = *reinterpret_cast<const f32x4 *>(p.bias + n8);
             bq1 = *reinterpret_cast<const f32x4 *>(p.bias + n8 + 4);
         }
-#pragma unroll
-        for (int rnd = 0; rnd < C::NRND; ++rnd) {
-            if (DEADROWS && half_live && C::MTL * rnd >= 2) break;       // (wave uniform, the same for every wave of the workgroup) no image rows in this round's MFMA tiles
-            if (rnd) __syncthreads();                    // round 0's readers are done
-            // publish: block (mtl, channel tile hh * NTW + nt), position xi: [4 register quads][64 lanes] x 16 B, slot XOR-swizzled
+        // publish: block (mtl, channel tile hh * NTW + nt), position xi: [4 register quads][64 lanes] x 16 B, slot XOR-swizzled
+        auto publish = [&](auto rnd_) __attribute__((always_inline)) {
+            constexpr int rnd = decltype(rnd_)::value;
+            unsigned char *const xr = xch + (C::EPI2 ? (rnd & 1) * C::XCH_ROUND : 0);
 #pragma unroll
             for (int mtl = 0; mtl < C::MTL; ++mtl)
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
                     const int blk = mtl * (NH * NTW) + hh * NTW + nt;
-                    unsigned char *base = xch + (blk * A + xi) * 4096;
+                    unsigned char *base = xr + (blk * A + xi) * 4096;
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
                         const f32x16 &t = acc[C::MTL * rnd + mtl][nt];
@@ -754,9 +758,23 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
                         *reinterpret_cast<f32x4 *>(base + r4 * 1024 + slot * 16) = f32x4{t[4 * r4], t[4 * r4 + 1], t[4 * r4 + 2], t[4 * r4 + 3]};
                     }
                 }
-            __syncthreads();
+        };
+        if constexpr (C::EPI2) { publish(std::integral_constant<int, 0>{}); __syncthreads(); }
+        static_for<0, C::NRND>([&](auto rnd_) __attribute__((always_inline)) {
+            constexpr int rnd = decltype(rnd_)::value;
+            if (DEADROWS && half_live && C::MTL * rnd >= 2) return;      // (wave uniform, the same for every wave of the workgroup) no image rows in this round's MFMA tiles
+            if constexpr (C::EPI2) {
+                // the other buffer's readers (round rnd - 1) passed the barrier at the end of their round
+                if constexpr (rnd + 1 < C::NRND) publish(std::integral_constant<int, rnd + 1>{});
+            } else {
+                if (rnd) __syncthreads();                // round 0's readers are done
+                publish(rnd_);
+                __syncthreads();
+            }
+            unsigned char *const xch = xsm + C::XCH_OFF + (C::EPI2 ? (rnd & 1) * C::XCH_ROUND : 0);
+            [&]() __attribute__((always_inline)) {
             // finish
-            if (part >= C::NPART || (BSVD_WX_ABL & 4)) continue;
+            if (part >= C::NPART || (BSVD_WX_ABL & 4)) return;
             constexpr int JN = M / C::NPART;             // columns per finisher
             const int j0 = part * JN;
 #pragma unroll
@@ -829,7 +847,9 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
                     }
                 }
             }
-        }
+            }();
+            if constexpr (C::EPI2 && rnd + 1 < C::NRND) __syncthreads();      // this round's readers are done; the next round's tiles are published
+        });
     };
     using std::integral_constant;
     if (p.epilogue == BSVD_EPI_PS_ADD) {
