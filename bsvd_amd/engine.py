@@ -35,6 +35,10 @@ def head_fusable(inc0, inc3, precision):
             and not inc3.tsm and inc3.epilogue == EPI_PLAIN and inc0.act == inc3.act)
 
 
+# Forms of the wide layers PackedNet accepts.  For users: "direct", "wino2" (default of arch.BSVD), "wino4", "wino6", "wino26" (F(2,3) on the
+# 128 -> 128 layers, F(6,3) on the wider ones).  Measurement / test variants of the same arithmetic (bit-identical to their base form): "wino2h" /
+# "wino6h" always the 8-row tile, "wino2n" never the persistent form, "wino2p" always, "wino2s" 4-wave workgroups, "wino2b" / "wino4b" the
+# all-positions-per-wave kernel (conv3x3_wino.hip).
 WIDE_CONV = ("direct", "wino2", "wino4", "wino6", "wino2b", "wino4b", "wino2s", "wino2h", "wino2p", "wino2n", "wino6h", "wino26")
 
 
@@ -42,7 +46,7 @@ WINO_MIN_CIN = 128     # narrowest layer the Winograd form takes (engine.PackedN
 
 
 def wino_eligible(sp, precision, min_cin=WINO_MIN_CIN):
-    """Layers the 1-D Winograd kernel (conv3x3_wino.hip) can take: the wide stride-1 layers of the split-fp16 mode --
+    """Layers the 1-D Winograd kernels (conv3x3_winox.hip) can take: the wide stride-1 layers of the split-fp16 mode --
     the temporal-fusion convs (bsvd_arch.py:21-50) and the UpBlock convs (:257-267) at >= 128 input channels.  The choice
     depends on the LAYER only (never on the clip length or frame size), so that every schedule -- clip, stream, sharded,
     MIMO -- runs the same arithmetic per layer and stays bit-identical to the others."""
@@ -141,7 +145,6 @@ class HipExecutor:
         # tuning override of the direct form's fat-tile threshold (BsvdConvArgs.fat_min_wgs; 0 = library default).  Read HERE, on the
         # host side of the ABI, once per executor -- the library itself reads no environment
         self.fat_min_wgs = int(os.environ.get("BSVD_FAT_MIN_WGS", "0") or 0)
-        self.wino_full_tile = False  # build_args: F(2,3) launches never take the half-height tile (set by the two-branch stream step)
         self.record_variants = False     # profiling aid: ask the library which kernel instantiation each conv uses
         self.last_variant = None
 
@@ -241,9 +244,11 @@ class HipExecutor:
         return _lib.BsvdConvArgs
 
     def build_args(self, sp, x, halo_prev=None, halo_next=None, extra=None, extra_pstride=0, extra_cstride=1,
-                   x_planar=False, y_planar=None, out=None, alloc=True, head=None):
+                   x_planar=False, y_planar=None, out=None, alloc=True, head=None, shared_chip=False):
         """Validates one fused layer and fills its ``BsvdConvArgs``; returns (args, y).  ``alloc=False`` leaves ``y`` (and
-        ``args.y``) unset for the caller to supply per launch (the stream plan's exit layer)."""
+        ``args.y``) unset for the caller to supply per launch (the stream plan's exit layer).  ``shared_chip``: the launch runs
+        beside another graph branch -- a Winograd layer then keeps its full tile whatever the grid (same bits; CUs its grid
+        leaves idle are the other branch's)."""
         a = _lib.BsvdConvArgs()
         if not x.is_contiguous():
             raise ValueError("%s: input must be contiguous" % sp.key)
@@ -305,8 +310,8 @@ class HipExecutor:
             a.w_packed = wp.data_ptr()
         else:
             a.w_wino_packed, a.wino_m = self.packed.wino[sp.key].data_ptr(), self.packed.wino_layer_abi[sp.key]
-            if self.wino_full_tile and a.wino_m in (2, 6):
-                a.wino_m += 40        # this launch shares the chip with another graph branch: never the half-height tile (same bits)
+            if shared_chip and a.wino_m in (2, 6):
+                a.wino_m += 40        # never the half-height tile
         if extra is not None:
             a.extra = extra.data_ptr()
             a.extra_frame_stride = extra[0].numel()

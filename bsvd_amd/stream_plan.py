@@ -244,12 +244,8 @@ class StreamEngine:
             plan = _Plan(rec)
             if self.hip:
                 plan.args = (self.ex.lib_args_type() * max(plan.n, 1))()
-                self.ex.wino_full_tile = shared_chip
-                try:
-                    for i, r in enumerate(rec):
-                        plan.args[i], _ = self.ex.build_args(*r[:9], out=r[9], head=r[10] if len(r) > 10 else None)
-                finally:
-                    self.ex.wino_full_tile = False
+                for i, r in enumerate(rec):
+                    plan.args[i], _ = self.ex.build_args(*r[:9], out=r[9], head=r[10] if len(r) > 10 else None, shared_chip=shared_chip)
             self.plans[sig] = plan
         return y, sig, plan
 
