@@ -769,8 +769,35 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
             } else {
                 if (rnd) __syncthreads();                // round 0's readers are done
                 publish(rnd_);
-                __syncthreads();
             }
+            // PixelShuffle + skip: the skip values of this round's pixels are requested HERE, in front of the barrier and the exchange reads (asked
+            // for at the point of use, each of the 8 requests per wave and tile stood exposed for a DRAM round trip)
+            constexpr int JN_ = M / C::NPART;
+            [[maybe_unused]] f32x4 skh[2][JN_], skl[2][JN_];
+#ifndef BSVD_WX_SKIPPF
+#define BSVD_WX_SKIPPF 1
+#endif
+            constexpr bool SKIPPF = BSVD_WX_SKIPPF && M == 2 && !PERSIST;        // (F(4,3) / F(6,3): the 32-48 registers it holds spill)
+            if constexpr (EPI == BSVD_EPI_PS_ADD && SKIPPF) {
+                if (has_skip && part < C::NPART) {
+#pragma unroll
+                    for (int sidx = 0; sidx < 2; ++sidx) {
+                        const int m = (lane + 64 * sidx) >> 2;
+                        const int oy = oy0 + 4 * (C::MTL * rnd + mtl) + (m >> 3);
+#pragma unroll
+                        for (int jj = 0; jj < JN_; ++jj) {
+                            const int ox = ox0 + M * (m & 7) + part * JN_ + jj;
+                            const bool live = oy < p.Ho && ox < p.Wo && n8 < p.Cout;
+                            const int sub = n8 / Cq, c8 = n8 - sub * Cq;
+                            const int64_t upix = (int64_t)(2 * oy + (sub >> 1)) * (2 * p.Wo) + (2 * ox + (sub & 1));
+                            const float *ep = p.extra + (int64_t)f * p.extra_fs + upix * p.extra_ps + coff16(c8);
+                            skh[sidx][jj] = live ? *reinterpret_cast<const f32x4 *>(ep) : f32x4{0.f, 0.f, 0.f, 0.f};
+                            skl[sidx][jj] = live ? *reinterpret_cast<const f32x4 *>(ep + 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                    }
+                }
+            }
+            if constexpr (!C::EPI2) __syncthreads();
             unsigned char *const xch = xsm + C::XCH_OFF + (C::EPI2 ? (rnd & 1) * C::XCH_ROUND : 0);
             [&]() __attribute__((always_inline)) {
             // finish
@@ -824,9 +851,15 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
                         const int64_t upix = (int64_t)(2 * oy + (sub >> 1)) * (2 * p.Wo) + (2 * ox + (sub & 1));
                         dst = p.y + (int64_t)f * p.y_fs + upix * Cq + coff16(c8);
                         if (has_skip && live) {
-                            const float *ep = p.extra + (int64_t)f * p.extra_fs + upix * p.extra_ps + coff16(c8);
-                            const f16x8 eh = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(ep));
-                            const f16x8 el = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(ep + 8));
+                            f16x8 eh, el;
+                            if constexpr (SKIPPF) {
+                                eh = __builtin_bit_cast(f16x8, skh[sidx][jj]);
+                                el = __builtin_bit_cast(f16x8, skl[sidx][jj]);
+                            } else {
+                                const float *ep = p.extra + (int64_t)f * p.extra_fs + upix * p.extra_ps + coff16(c8);
+                                eh = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(ep));
+                                el = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(ep + 8));
+                            }
 #pragma unroll
                             for (int k = 0; k < 8; ++k) v[k] += (float)eh[k] + (float)el[k];
                         }
