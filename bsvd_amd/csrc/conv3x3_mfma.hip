@@ -1051,6 +1051,22 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         if (p.y_planar_ch > 0) {
             if (lh == 0 && n0 == 0) {
                 const int64_t plane = (int64_t)p.Ho * p.Wo;
+                // the residual base of every pixel of this lane FIRST (split16: channels 0..3 are one 8-byte hi and one 8-byte lo piece): read at
+                // the point of use, between stores the compiler must assume alias them, the tile's bases were C::MT x channels dependent round trips
+                typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+                [[maybe_unused]] f16x4_t bh[C::MT], bl[C::MT];
+                const bool split_base = p.epilogue == BSVD_EPI_RESID && p.extra_split;
+                if (split_base) {
+#pragma unroll
+                    for (int mt = 0; mt < C::MT; ++mt) {
+                        const int oy = oy0 + 2 * C::MT * wm + 2 * mt + (li >> 4), ox = ox0 + (li & 15);
+                        bh[mt] = bl[mt] = f16x4_t{0, 0, 0, 0};
+                        if (oy >= p.Ho || ox >= p.Wo) continue;
+                        const _Float16 *e = reinterpret_cast<const _Float16 *>(p.extra + (int64_t)f * p.extra_fs + ((int64_t)oy * p.Wo + ox) * p.extra_ps);
+                        bh[mt] = *reinterpret_cast<const f16x4_t *>(e);
+                        bl[mt] = *reinterpret_cast<const f16x4_t *>(e + 16);
+                    }
+                }
 #pragma unroll
                 for (int mt = 0; mt < C::MT; ++mt) {
                     const int oy = oy0 + 2 * C::MT * wm + 2 * mt + (li >> 4), ox = ox0 + (li & 15);
@@ -1062,9 +1078,8 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                         float v = apply_act(acc[mt][0][n] + (p.bias ? p.bias[n] : 0.f), p.act);
                         if (p.epilogue == BSVD_EPI_RESID && n < p.resid_ch) {
                             float base;
-                            if (p.extra_split) {       // split16 NHWC base: channel n < 16 lives in chunk 0
-                                const _Float16 *e = reinterpret_cast<const _Float16 *>(p.extra + (int64_t)f * p.extra_fs + opix * p.extra_ps);
-                                base = (float)e[n] + (float)e[16 + n];
+                            if (split_base) {          // split16 NHWC base: channel n < 16 lives in chunk 0
+                                base = (float)bh[mt][n] + (float)bl[mt][n];
                             } else {
                                 base = p.extra[(int64_t)f * p.extra_fs + opix * p.extra_ps + (int64_t)n * p.extra_cs];
                             }
