@@ -273,7 +273,16 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
     //  the in-order vmcnt, for the previous round's stores.  A tile table in LDS read back with v_readfirstlane removed the scalar spills
     //  and cost more than it saved (the reads' lgkmcnt(0) waits sit inside the MFMA steps).  Measured 6-13 % slower than one tile per
     //  workgroup; kept for the record, never selected: BSVD_WX_PERSIST_MIN.)
-    auto next_tile = [&]() __attribute__((always_inline)) { return decode_tile(PERSIST ? jt + xcd_wgs : 0x3fffffff); };
+    auto next_tile = [&]() __attribute__((always_inline)) {
+        if constexpr (PERSIST) {
+            return decode_tile(jt + xcd_wgs);
+        } else {              // no next tile: T with zero-size sources (no decoding -- this sits in the K loop's last iterations)
+            XTile t = T;
+            t.S.cur_bytes = t.S.prev_bytes = t.S.next_bytes = 0u;
+            t.S.ncb = 0;
+            return t;
+        }
+    };
     const unsigned w_bytes = (unsigned)p.Cin * (unsigned)(3 * A) * (unsigned)p.Cout * 4u;
 
     // ---- weights of this wave's position: rows of the MFMA's A operand = output channels (conv3x3_mfma.hip: `chan`)
