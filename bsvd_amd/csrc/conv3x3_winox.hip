@@ -598,14 +598,20 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
             static_for<0, 3>([&](auto k_) __attribute__((always_inline)) { load_b((cb + 1) * 3 + decltype(k_)::value, bring[decltype(k_)::value]); });
         };
         // transform step of this iteration: finish chunk cb + 1 (requested PP iterations ago) into the other buffer, request chunk cb + 1 + PP
+#ifndef BSVD_WX_TAILSKIP
+#define BSVD_WX_TAILSKIP 1
+#endif
 #ifndef BSVD_WX_PRIO
 #define BSVD_WX_PRIO 0     // s_setprio level of the transform phase (the MFMA steps run at 0): a wave streaming MFMAs wins the VALU arbitration every cycle
 #endif
         auto xform = [&]() __attribute__((always_inline)) {
             if (BSVD_WX_PRIO) __builtin_amdgcn_s_setprio(BSVD_WX_PRIO);
             const int tl = lane_id();
-            chunk_finish(cb + 1, pnext, setv, PAll{}, tl);
-            if (!(BSVD_WX_ABL & 64)) chunk_load(cb + 1 + PP, setv, PAll{}, tl);
+            // (one tile per workgroup: nothing behind the tile's last chunk -- its transform and the requests of the last PP + 1 iterations
+            //  would be zeros from zero-size descriptors, a whole transform phase per tile for nothing)
+            constexpr bool TS_FIN = BSVD_WX_TAILSKIP && !PERSIST, TS_LD = TS_FIN && M == 2;      // (F(6,3) with the request skip too: 25 spills)
+            if (!TS_FIN || cb + 1 < ncb) chunk_finish(cb + 1, pnext, setv, PAll{}, tl);
+            if (!(BSVD_WX_ABL & 64) && (!TS_LD || cb + 1 + PP < ncb)) chunk_load(cb + 1 + PP, setv, PAll{}, tl);
             if (BSVD_WX_PRIO) __builtin_amdgcn_s_setprio(0);
         };
         // (one copy of the MFMA steps between two conditional transforms: an if / else with the phases in opposite orders made the
