@@ -143,6 +143,9 @@ __device__ __forceinline__ u32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned vo
 //   decode   d = (float)hi + (float)lo                      -> v_fma_mix_f32   d, hi.h[SEL], 1.0, lo.h[SEL]
 //   residual lo' = fp16(v - (float)hi') for a pair (v0, v1) -> v_fma_mixlo_f16 / v_fma_mixhi_f16  (v - hi' is exact in fp32, so this is
 //            bit for bit the (_Float16)(v - (float)hi') of the plain form: 3 instructions per value there, 1 here)
+#ifndef BSVD_WX_MIXASM
+#define BSVD_WX_MIXASM 1
+#endif
 struct MixConst { float one, mone; };
 template <int SEL>
 __device__ __forceinline__ float dec_pair(unsigned h, unsigned l, const MixConst &k)
@@ -156,9 +159,17 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned &hp, uns
     typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
     static_assert(BSVD_TUNE_LO_BITS >= 10, "the mixed-precision split keeps all bits of the lo halves");
     const f16x2_t hv = {(_Float16)v0, (_Float16)v1};                                  // v_cvt_pk_f16_f32 (round to nearest even)
-    const f16x2_t lv = {(_Float16)__builtin_fmaf((float)hv[0], k.mone, v0), (_Float16)__builtin_fmaf((float)hv[1], k.mone, v1)};
     hp = __builtin_bit_cast(unsigned, hv);
+#if BSVD_WX_MIXASM
+    // both residuals straight from the PACKED hi pair (op_sel picks its halves): 3 instructions per channel pair.  Left to itself hipcc converts
+    // each channel a second time (v_cvt_f16_f32) to have the fma_mix source in a low half: 5.  Same arithmetic, same bits.  The results go to
+    // ds_write only (hardware-interlocked; no software wait states involved)
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hp), "s"(k.mone), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hp), "s"(k.mone), "v"(v1));
+#else
+    const f16x2_t lv = {(_Float16)__builtin_fmaf((float)hv[0], k.mone, v0), (_Float16)__builtin_fmaf((float)hv[1], k.mone, v1)};
     lp = __builtin_bit_cast(unsigned, lv);
+#endif
 }
 
 struct XChunkSrc {         // wave-uniform source of one 16-channel chunk (temporal-shift gather: next / previous / this frame) + its tile's origin
