@@ -519,7 +519,12 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
         }
         if constexpr (NROT > 0 && (decltype(part_)::value & 2)) {
             const int rs = rot_slot(cc);
-            if (rs >= 0 && !half_live) item_load(c, ROT0 + rs * 64 + tl, true, raw_rot[SET]);        // (left-over blocks: patch rows 16, 17)
+#ifndef BSVD_WX_UNCOND
+#define BSVD_WX_UNCOND 0       // 1: every wave issues the SAME number of activation requests per chunk on every path (a wave without a left-over block: 2 A
+                               // requests from the out-of-range sentinel; behind the last chunk: from zero-size descriptors): see BSVD_WX_LOADLAST (slower)
+#endif
+            if constexpr (BSVD_WX_UNCOND && !DEADROWS) item_load(c, ROT0 + (rs >= 0 ? rs : 0) * 64 + tl, rs >= 0, raw_rot[SET]);
+            else if (rs >= 0 && !half_live) item_load(c, ROT0 + rs * 64 + tl, true, raw_rot[SET]);        // (left-over blocks: patch rows 16, 17)
         }
     };
     auto chunk_finish = [&](int cc, unsigned char *vbuf, int SET, auto part_, int tl) __attribute__((always_inline)) {
@@ -615,14 +620,23 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
 #ifndef BSVD_WX_PRIO
 #define BSVD_WX_PRIO 0     // s_setprio level of the transform phase (the MFMA steps run at 0): a wave streaming MFMAs wins the VALU arbitration every cycle
 #endif
-        auto xform = [&]() __attribute__((always_inline)) {
+#ifndef BSVD_WX_LOADLAST
+#define BSVD_WX_LOADLAST 0     // 1: the activation requests of an iteration go out BEHIND the MFMA steps in both phase orders (only the finishing moves
+                               // in front of them for the second phase).  Background: hipcc's vmcnt in front of the first MFMA of a phase is vmcnt(11) --
+                               // it drains every activation request the wave has in flight, because the branches around the requests (interior / edge
+                               // tile, left-over block or not) make its counts conservative.  With this, BSVD_WX_UNCOND and BSVD_WX_XIN=0 the counts
+                               // come out exact (vmcnt(35): 24 requests stay in flight) -- and the kernel is 8-10 % SLOWER: the drain is not what a
+                               // wave waits for (the other wave of the SIMD runs meanwhile), early requests are what counts
+#endif
+        auto xform = [&](auto part_) __attribute__((always_inline)) {      // part_: 1 finish, 2 request, 3 both
+            constexpr int XP = decltype(part_)::value;
             if (BSVD_WX_PRIO) __builtin_amdgcn_s_setprio(BSVD_WX_PRIO);
             const int tl = lane_id();
             // (one tile per workgroup: nothing behind the tile's last chunk -- its transform and the requests of the last PP + 1 iterations
             //  would be zeros from zero-size descriptors, a whole transform phase per tile for nothing)
-            constexpr bool TS_FIN = BSVD_WX_TAILSKIP && !PERSIST, TS_LD = TS_FIN && M == 2;      // (F(6,3) with the request skip too: 25 spills)
-            if (!TS_FIN || cb + 1 < ncb) chunk_finish(cb + 1, pnext, setv, PAll{}, tl);
-            if (!(BSVD_WX_ABL & 64) && (!TS_LD || cb + 1 + PP < ncb)) chunk_load(cb + 1 + PP, setv, PAll{}, tl);
+            constexpr bool TS_FIN = BSVD_WX_TAILSKIP && !PERSIST, TS_LD = TS_FIN && M == 2 && !BSVD_WX_UNCOND;      // (F(6,3) with the request skip too: 25 spills)
+            if constexpr (XP & 1) if (!TS_FIN || cb + 1 < ncb) chunk_finish(cb + 1, pnext, setv, PAll{}, tl);
+            if constexpr (XP & 2) if (!(BSVD_WX_ABL & 64) && (!TS_LD || cb + 1 + PP < ncb)) chunk_load(cb + 1 + PP, setv, PAll{}, tl);
             if (BSVD_WX_PRIO) __builtin_amdgcn_s_setprio(0);
         };
         // (one copy of the MFMA steps between two conditional transforms: an if / else with the phases in opposite orders made the
@@ -728,13 +742,15 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
             continue;
         }
         [[maybe_unused]] const unsigned long long t0 = WXT_NOW();
-        if (!(BSVD_WX_ABL & 1) && phase != 0) xform();
+        using XFin = std::integral_constant<int, BSVD_WX_LOADLAST ? 1 : 3>;
+        if (!(BSVD_WX_ABL & 1) && phase != 0) xform(XFin{});
         __builtin_amdgcn_sched_barrier(0);
         [[maybe_unused]] const unsigned long long t1 = WXT_NOW();
         if (!(BSVD_WX_ABL & 2)) mfma_phase(std::integral_constant<int, C::MT>{});
         __builtin_amdgcn_sched_barrier(0);
         [[maybe_unused]] const unsigned long long t2 = WXT_NOW();
-        if (!(BSVD_WX_ABL & 1) && phase == 0) xform();
+        if (!(BSVD_WX_ABL & 1) && phase == 0) xform(XFin{});
+        if constexpr (BSVD_WX_LOADLAST) if (!(BSVD_WX_ABL & 1)) xform(std::integral_constant<int, 2>{});
         [[maybe_unused]] const unsigned long long t3 = WXT_NOW();
         if (!(BSVD_WX_ABL & 8)) __syncthreads();
 #ifdef BSVD_WX_TL
