@@ -554,7 +554,8 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
 #ifndef BSVD_WX_PHASE
 #define BSVD_WX_PHASE 0    // which waves run the chunk's phases in opposite order: 0 (wid >> 2), 1 wid, 2 (wid >> 1)   (A/B: who shares a SIMD?)
 #endif
-    const int phase = C::NW == 4 ? (wid >> 1) : (BSVD_WX_PHASE == 0 ? (wid >> 2) : BSVD_WX_PHASE == 1 ? wid : (wid >> 1)) % C::NPH;
+    const int phase = BSVD_WX_PHASE == 3 ? 1 : BSVD_WX_PHASE == 4 ? 0 :       // 3 / 4: every wave transform-first / MFMA-first (the SIMD's waves in step)
+                      C::NW == 4 ? (wid >> 1) : (BSVD_WX_PHASE == 0 ? (wid >> 2) : BSVD_WX_PHASE == 1 ? wid : (wid >> 1)) % C::NPH;
     // (the loop body is written out in the loop, not as a lambda: one more level of by-reference closure nesting and hipcc no longer
     //  promotes the captured locals -- kernel parameters, pointers, the raw sets -- out of private memory)
     [[maybe_unused]] const unsigned long long tl_loop = WXT_NOW();
