@@ -1214,15 +1214,28 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 for (int j = 0; j < 8; ++j) e[j >> 2][j & 3] = ep[(int64_t)j * p.extra_cs];
             }
         };
+        // RESID (DenBlock 1's last layer, bsvd_arch.py:408-414): the residual base of an item, requested one item ahead like the skip operand
+        // (read at its point of use it sat between two items' stores, which the compiler must assume alias it: a dependent round trip per item)
+        auto resid_load = [&](const Item &t, f32x4 (&e)[2]) {
+            e[0] = e[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!(t.live && t.n8 == 0)) return;
+            const float *ep = p.extra + (int64_t)f * p.extra_fs + t.opix * p.extra_ps;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < p.resid_ch) e[j >> 2][j & 3] = ep[(int64_t)j * p.extra_cs];
+        };
         constexpr int NITEM = C::MT * C::NT * 2;
         f32x4 ecur[2], enxt[2];
         [[maybe_unused]] unsigned long long tlp_acc[3] = {0, 0, 0};
         if constexpr (EPI == BSVD_EPI_PS_ADD) skip_load(item_of(0), ecur);
+        if constexpr (EPI == BSVD_EPI_RESID) resid_load(item_of(0), ecur);
 #pragma unroll
         for (int i = 0; i < NITEM; ++i) {
             const int sidx = i & 1, nt = (i >> 1) % C::NT, mt = (i >> 1) / C::NT;
             if constexpr (EPI == BSVD_EPI_PS_ADD)
                 if (i + 1 < NITEM) skip_load(item_of(i + 1), enxt);
+            if constexpr (EPI == BSVD_EPI_RESID)
+                if (i + 1 < NITEM) resid_load(item_of(i + 1), enxt);
             float v[8];
             TLP_BEGIN();
             if constexpr (PREC == 1) {
@@ -1280,8 +1293,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     if (t.n8 == 0) {                                         // base: fp32 with generic strides
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
-                            if (j < p.resid_ch)
-                                v[j] = p.extra[(int64_t)f * p.extra_fs + t.opix * p.extra_ps + (int64_t)j * p.extra_cs] - v[j];
+                            if (j < p.resid_ch) v[j] = ecur[j >> 2][j & 3] - v[j];
                     }
                 }
                 if constexpr (PREC == 1) {
@@ -1319,7 +1331,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     *reinterpret_cast<f32x4 *>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
                 }
             }
-            if constexpr (EPI == BSVD_EPI_PS_ADD) { ecur[0] = enxt[0]; ecur[1] = enxt[1]; }
+            if constexpr (EPI == BSVD_EPI_PS_ADD || EPI == BSVD_EPI_RESID) { ecur[0] = enxt[0]; ecur[1] = enxt[1]; }
             TLP_MARK(2);
 #if !defined(BSVD_TIMELINE) || BSVD_TIMELINE != 2
             if (i == 0) TL(5);

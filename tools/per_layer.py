@@ -25,7 +25,7 @@ def main():
         torch.cuda.synchronize()
         timer.detach()
     per = {}
-    for sp, T, Hh, Ww, e0, e1, name in timer.records:
+    for sp, T, Hh, Ww, e0, e1, name, _zs in timer.records:
         d = per.setdefault(sp.key, [0.0, 2.0 * sp.macs(Hh, Ww) * T, name, sp, Hh, Ww])
         d[0] += e0.elapsed_time(e1) / reps
     tot = sum(v[0] for v in per.values())
