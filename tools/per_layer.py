@@ -26,7 +26,10 @@ def main():
         timer.detach()
     per = {}
     for sp, T, Hh, Ww, e0, e1, name, _zs in timer.records:
-        d = per.setdefault(sp.key, [0.0, 2.0 * sp.macs(Hh, Ww) * T, name, sp, Hh, Ww])
+        flop = 2.0 * sp.macs(Hh, Ww) * T
+        if hasattr(sp, "sps"):          # the fused network entry: two layers in one launch, listed under the second one's key
+            sp = sp.sps[-1]
+        d = per.setdefault(sp.key, [0.0, flop, name, sp, Hh, Ww])
         d[0] += e0.elapsed_time(e1) / reps
     tot = sum(v[0] for v in per.values())
     print("%-34s %-44s %9s %8s %7s" % ("layer", "kernel", "ms", "TFLOP/s", "share"))
