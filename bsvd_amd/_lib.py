@@ -9,12 +9,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BSVD_HIP_LIB") or os.path.join(_HERE, "libbsvd_hip.so")   # env override: A/B tuning builds
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 BSVD_F32, BSVD_F16, BSVD_F16X3 = 0, 1, 2
 ACT = {"none": 0, "relu": 1, "relu6": 2}
 EPI_PLAIN, EPI_PS_ADD, EPI_RESID = 0, 1, 2
+BUILD_MEASURE = 1            # bsvd_build_info(): a -DBSVD_MEASURE build (tools/build_measure.sh), never the in-tree product library
 
-EXPORTS = ("bsvd_abi_version", "bsvd_conv_args_size", "bsvd_last_error", "bsvd_conv3x3", "bsvd_conv3x3_variant", "bsvd_packed_weight_elems", "bsvd_pack_weights",
+EXPORTS = ("bsvd_abi_version", "bsvd_conv_args_size", "bsvd_build_info", "bsvd_last_error", "bsvd_conv3x3", "bsvd_conv3x3_variant", "bsvd_packed_weight_elems", "bsvd_pack_weights",
            "bsvd_packed_head_weight_bytes", "bsvd_pack_head_weights", "bsvd_packed_wino_weight_elems", "bsvd_pack_weights_wino",
            "bsvd_nchw_to_nhwc", "bsvd_nhwc_to_nchw", "bsvd_halo_pack", "bsvd_halo_unpack", "bsvd_workspace_bytes",
            "bsvd_u8_to_planar", "bsvd_planar_to_u8", "bsvd_conv3x3_batch", "bsvd_graph_begin", "bsvd_graph_fork",
@@ -81,6 +82,8 @@ def load():
     lib.bsvd_abi_version.argtypes = []
     lib.bsvd_conv_args_size.restype = ctypes.c_int
     lib.bsvd_conv_args_size.argtypes = []
+    lib.bsvd_build_info.restype = ctypes.c_int
+    lib.bsvd_build_info.argtypes = []
     lib.bsvd_last_error.restype = ctypes.c_char_p
     lib.bsvd_last_error.argtypes = []
     lib.bsvd_conv3x3.restype = ctypes.c_int

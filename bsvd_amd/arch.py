@@ -50,9 +50,10 @@ def remove_registration_hooks():
     while _HOOK_HANDLES:
         _HOOK_HANDLES.pop().remove()
 
-# Arithmetic form of the wide stride-1 layers in the split mode (engine.wino_eligible): 'direct' (3-pass implicit GEMM), 'wino2' / 'wino4' /
-# 'wino6' (1-D Winograd F(2,3) / F(4,3) / F(6,3) along x, conv3x3_winox.hip), 'wino26' (F(2,3) on the 128 -> 128 layers, F(6,3) on the wider
-# ones); the other members of engine.WIDE_CONV are measurement / test variants.  wide_conv='auto' takes BSVD_WIDE_CONV or this.
+# Arithmetic form of the wide stride-1 layers in the split mode (engine.wino_eligible): 'direct' (3-pass implicit GEMM), 'wino2' /
+# 'wino6' (1-D Winograd F(2,3) / F(6,3) along x, conv3x3_winox.hip), 'wino26' (F(2,3) on the 128 -> 128 layers, F(6,3) on the wider
+# ones) = engine.WIDE_CONV.  wide_conv='auto' takes this default.  A constructor keyword only: no environment variable changes the form
+# (and with it the bits) behind a model's back; measurement variants (engine.MEASURE_WIDE_CONV) need a measurement build of the library.
 # F(2,3) gains in every schedule (clip +4 %, per-frame stream +5 % over 'direct'); F(6,3) is 1-4 % faster on clips and 6 % slower per
 # frame at 540 x 960.  One form per model: clip, stream and sharded schedules stay bit-identical to each other.
 WIDE_CONV_DEFAULT = "wino2"
@@ -119,9 +120,9 @@ class _HipNet(nn.Module):
         if precision not in ("auto", "fp32", "f16x3"):
             raise ValueError("precision must be 'auto', 'fp32' or 'f16x3'")
         if wide_conv == "auto":
-            wide_conv = os.environ.get("BSVD_WIDE_CONV", WIDE_CONV_DEFAULT)
-        from .engine import WIDE_CONV
-        if wide_conv not in WIDE_CONV:
+            wide_conv = WIDE_CONV_DEFAULT
+        from .engine import WIDE_CONV, MEASURE_WIDE_CONV
+        if wide_conv not in WIDE_CONV and wide_conv not in MEASURE_WIDE_CONV:      # (measurement names: PackedNet checks the library build)
             raise ValueError("wide_conv must be 'auto' or one of %s" % (WIDE_CONV,))
         self.wide_conv = wide_conv
         if norm not in ("none", "bn"):
@@ -135,20 +136,35 @@ class _HipNet(nn.Module):
         # config); a temporal-fusion layer needs whole 16-channel chunks per temporal source: fold % 16 == 0
         bad = [l.key for l in net.layers if l.tsm and l.fold % 16 and not (l.fold == 8 and l.cout_pad <= 64)]
         split_ok = not bad and net.net_in_ch in (3, 4) and net.out_ch <= 4
-        self.precision_requested = precision
-        if precision == "auto":
-            # the split-fp16 mode carries fp32-class accuracy (2-6e-5 vs the reference goldens, budget 1e-3) at ~3x the
-            # rate: take it whenever the network's channel layout admits it (the c64 / c32-sized networks do)
-            precision = "f16x3" if split_ok else "fp32"
-        elif precision == "f16x3" and not split_ok:
-            raise ValueError("precision='f16x3' needs temporal-fusion layers with fold % 16 == 0 or 64 channels (fold 8), "
-                             "i.e. chns[1:] = (64|128k, 128k) like the c64 and c32 networks, and <= 4 input/output "
-                             "channels; offending layers: %s" % (bad[:3],))
-        self.precision = precision
-        self._precision_init = precision       # what __init__ resolved; a weight-range fallback of 'auto' to fp32 lasts one pack only
+        self._split_ok, self._split_bad = split_ok, bad
         self._packed = None
         self._packed_sig = None
         self._exec = None
+        self.precision = precision             # (property: resolves 'auto', validates, see below)
+
+    # ``precision`` is a property: the constructor keyword AND a later ``model.precision = 'fp32'`` go through the same validation,
+    # and the next forward re-packs the weights in the new mode (the pack signature holds the resolved request).  Reading it gives the
+    # mode that RUNS: 'f16x3' | 'fp32' -- after a weight-range fallback of 'auto' that is 'fp32' until an in-range checkpoint is loaded.
+    @property
+    def precision(self):
+        return self.__dict__.get("_precision_eff")
+
+    @precision.setter
+    def precision(self, precision):
+        if precision not in ("auto", "fp32", "f16x3"):
+            raise ValueError("precision must be 'auto', 'fp32' or 'f16x3'")
+        requested = precision
+        if precision == "auto":
+            # the split-fp16 mode carries fp32-class accuracy (2-6e-5 vs the reference goldens, budget 1e-3) at ~3x the
+            # rate: take it whenever the network's channel layout admits it (the c64 / c32-sized networks do)
+            precision = "f16x3" if self._split_ok else "fp32"
+        elif precision == "f16x3" and not self._split_ok:
+            raise ValueError("precision='f16x3' needs temporal-fusion layers with fold % 16 == 0 or 64 channels (fold 8), "
+                             "i.e. chns[1:] = (64|128k, 128k) like the c64 and c32 networks, and <= 4 input/output "
+                             "channels; offending layers: %s" % (self._split_bad[:3],))
+        self.precision_requested = requested
+        self.__dict__["_precision_eff"] = precision
+        self._precision_init = precision       # what the request resolved to; a weight-range fallback of 'auto' to fp32 lasts one pack only
 
     @staticmethod
     def weight_init(m):
@@ -226,7 +242,7 @@ class _HipNet(nn.Module):
         if self._packed is None or self._packed_sig != sig:
             # every re-pack starts from the precision the constructor resolved: 'auto' that fell back to exact fp32 because ONE
             # checkpoint's folded weights left fp16's range takes the split mode again when an in-range checkpoint is loaded
-            self.precision = self._precision_init
+            self.__dict__["_precision_eff"] = self._precision_init
             # the ring/graph engines of the stream schedule bake the packed-weight addresses into their launch plans: drop them
             # BEFORE the old pack is freed (a new executor may even reuse the old one's id())
             if getattr(self, "_stream_engs", None):
@@ -242,7 +258,7 @@ class _HipNet(nn.Module):
                     if self.precision_requested == "auto":
                         warnings.warn("bsvd_amd: max |weight| after the BatchNorm fold is %.3g, outside fp16's range: "
                                       "precision='auto' falls back to exact fp32 for this network" % wmax)
-                        self.precision = "fp32"
+                        self.__dict__["_precision_eff"] = "fp32"
                     else:
                         raise ValueError("precision='f16x3': max |weight| after the BatchNorm fold is %.3g, outside fp16's "
                                          "range (use precision='fp32' or 'auto')" % wmax)

@@ -85,7 +85,8 @@ __global__ void pack_weights_split_kernel(const float *__restrict__ w, const flo
         } else {
             ok = ok && np < Cout;
         }
-        const float v = ok ? w[((int64_t)n * Cin + c) * 9 + tap] : 0.f;
+        float v = ok ? w[((int64_t)n * Cin + c) * 9 + tap] : 0.f;
+        v = fminf(fmaxf(v, -65504.f), 65504.f);        // fp16 range: saturate, never an (inf, NaN) pair (hosts refuse such weights first)
         const _Float16 hi = (_Float16)v;
         wp[i] = part ? lo_keep((_Float16)(v - (float)hi)) : hi;
         if (bp && i < Cout_pad) {
@@ -136,6 +137,9 @@ __global__ void pack_weights_wino_kernel(const float *__restrict__ w, const floa
             const float *g = w + ((int64_t)n * Cin + c) * 9 + ky * 3;
             u = G.g[xi][0] * (double)g[0] + G.g[xi][1] * (double)g[1] + G.g[xi][2] * (double)g[2];
         }
+        // fp16 range: U = G g reaches 1.5x (F(2,3)) .. 15x (F(6,3)) the largest weight.  Saturate instead of packing (inf, NaN); hosts keep
+        // such a layer on the direct form (engine.PackedNet tests max |w| x the form's largest |G| row sum against fp16's range)
+        u = u > 65504.0 ? 65504.0 : (u < -65504.0 ? -65504.0 : u);
         const _Float16 hi = (_Float16)u;
         wp[i] = part ? lo_keep((_Float16)(u - (double)hi)) : hi;
         if (bp && i < Cout_pad) {
@@ -263,6 +267,7 @@ __global__ void pack_head_weights_kernel(const float *__restrict__ w, const floa
         const int k = 16 * sidx + 8 * kb + j, tap = k >> 2, c = k & 3;
         float v = 0.f;
         if (ch < Cmid && tap < 9 && c < Cin) v = w[((int64_t)ch * Cin + c) * 9 + tap];
+        v = fminf(fmaxf(v, -65504.f), 65504.f);
         const _Float16 hi = (_Float16)v;
         _Float16 *dst = wp + ((int64_t)(ps * 64 + lane)) * 16;
         dst[j] = hi;
@@ -289,6 +294,15 @@ extern "C" {
 int bsvd_abi_version(void) { return BSVD_ABI_VERSION; }
 
 int bsvd_conv_args_size(void) { return (int)sizeof(BsvdConvArgs); }
+
+int bsvd_build_info(void)
+{
+    int v = 0;
+#ifdef BSVD_MEASURE
+    v |= BSVD_BUILD_MEASURE;
+#endif
+    return v;
+}
 
 const char *bsvd_last_error(void) { return g_err; }
 
@@ -354,7 +368,10 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
     if (a->w_wino_packed) {      // Winograd form of a wide layer: explicit request, no silent fall-back to the direct kernel
         if (a->x_planar_ch > 0 || a->head_w_packed) { set_error("bsvd_conv3x3: w_wino_packed: not with a planar / fused entry"); return -19; }
         if (const char *why = wino_unsupported(p, a->stride)) { set_error("bsvd_conv3x3: w_wino_packed (F(%d,3)): %s", a->wino_m, why); return -19; }
-        return (p.wino_m >= 10 && p.wino_m < 20) ? launch_wino(p, (hipStream_t)stream, name, name_len) : launch_winox(p, (hipStream_t)stream, name, name_len);
+#ifdef BSVD_MEASURE
+        if (p.wino_m >= 10 && p.wino_m < 20) return launch_wino(p, (hipStream_t)stream, name, name_len);
+#endif
+        return launch_winox(p, (hipStream_t)stream, name, name_len);
     }
     if (a->x_planar_ch > 0 || a->y_planar_ch > 0) {
         if (a->x_planar_ch > 0 && a->y_planar_ch > 0) { set_error("bsvd_conv3x3: x_planar_ch and y_planar_ch are exclusive"); return -16; }

@@ -59,6 +59,31 @@ __host__ __device__ inline _Float16 lo_keep(_Float16 lo)
 #endif
 }
 
+// fp16 range of the split mode.  Every value is carried as hi = fp16(v), lo = fp16(v - hi); a conversion that overflows to +-inf turns
+// the pair into (inf, NaN) and every product it meets into NaN.  The stores of the direct kernel clamp to +-65504 first (v_med3_f32),
+// but the Winograd kernel converts TRANSFORMED values -- sums of up to 2x (F(2,3)), 3x (F(4,3)), 4.7x (F(6,3)) the activation range --
+// 12 to 24 times per transform item, where one more VALU instruction per value costs 3-4 % of the layer.  gfx9's MODE.FP16_OVFL
+// (bit 23: "an overflowed fp16 result is clamped to +-MAX_FP16, true infinities preserved") does it in the conversion itself:
+// hi saturates at +-65504 and lo = fp16(v - hi) carries the rest, up to another 65504: below 65504 nothing changes (same bits), in
+// (65504, 131008] a pair still represents v, at lo's own 11-bit precision (relative error <= 2^-13 instead of 2^-22: graceful), and
+// beyond it saturates -- no instruction, no inf, no NaN from finite inputs.  Set once at kernel entry by every kernel that produces
+// fp16 pairs; MFMAs (fp32 results) are not affected.  Verified on MI355X: tests/test_gpu_range.py.
+#ifndef BSVD_FP16_OVFL
+#define BSVD_FP16_OVFL 1
+#endif
+// The split STORES keep their explicit clamp to +-65504 (one v_med3_f32 per value of a layer without a bounded activation): a stored pair
+// then always has |lo| <= ulp(hi) / 2, i.e. full pair precision, whatever produced it.  0 = rely on the saturating conversions alone
+// (A/B knob: the epilogues do not wait for these instructions, r03 / r05 records).
+#ifndef BSVD_EPI_CLAMP
+#define BSVD_EPI_CLAMP 1
+#endif
+__device__ __forceinline__ void fp16_saturate_on()
+{
+#if BSVD_FP16_OVFL
+    __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1 /* hwreg(HW_REG_MODE, 23, 1) */, 1);
+#endif
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember, per device, the largest
 // size already granted for one kernel (`granted` = a zero-initialised static array of MAX_DEVICES atomics owned by
 // the launcher).  Thread-safe; a lost race only repeats an idempotent call.
@@ -79,11 +104,13 @@ inline hipError_t ensure_dynamic_lds(const void *fn, int bytes, std::atomic<int>
 // name != nullptr: dry run, only writes the kernel instantiation that would be launched
 int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *name = nullptr, int name_len = 0);
 
-// conv3x3_wino.hip
+// conv3x3_winox.hip (one transformed position per wave; wino_m 2 | 6, 42 | 46; measurement builds: more codes)
 const char *wino_unsupported(const ConvParams &p, int stride);     // nullptr = the Winograd kernel can run this layer
-int launch_wino(const ConvParams &p, hipStream_t stream, char *name = nullptr, int name_len = 0);
-// conv3x3_winox.hip (one transformed position per wave; wino_m 2 | 4 | 6)
 int launch_winox(const ConvParams &p, hipStream_t stream, char *name = nullptr, int name_len = 0);
+#ifdef BSVD_MEASURE
+// conv3x3_wino.hip (all positions per wave: the rejected first design, measurement builds only)
+int launch_wino(const ConvParams &p, hipStream_t stream, char *name = nullptr, int name_len = 0);
+#endif
 
 // conv3x3_edge_f32.hip
 int launch_head_f32(const ConvParams &p, int cin_real, hipStream_t stream);

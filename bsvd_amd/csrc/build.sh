@@ -11,8 +11,12 @@ OUT="${BSVD_OUT:-$ROOT/bsvd_amd/libbsvd_hip.so}"
 # objects live outside the package: build/obj (product), build/obj_ab<i> (tools/build_ab.sh variants)
 OBJ="$ROOT/build/obj${BSVD_OBJ_SUFFIX:-}"
 mkdir -p "$OBJ"
+# the product library: four translation units.  A measurement build (EXTRA_HIPCC_FLAGS contains -DBSVD_MEASURE, tools/build_measure.sh)
+# adds conv3x3_wino.hip (the rejected all-positions-per-wave Winograd kernel) and the variant instantiations of conv3x3_winox.hip
+SRCS="conv3x3_mfma conv3x3_winox conv3x3_edge_f32 bsvd_abi"
+case " ${EXTRA_HIPCC_FLAGS} " in *" -DBSVD_MEASURE"*) SRCS="$SRCS conv3x3_wino";; esac
 pids=()
-for src in conv3x3_mfma conv3x3_wino conv3x3_winox conv3x3_edge_f32 bsvd_abi; do
+for src in $SRCS; do
   if [ ! -f "$OBJ/$src.o" ] || [ "$HERE/$src.hip" -nt "$OBJ/$src.o" ] || \
      [ "$HERE/bsvd_internal.h" -nt "$OBJ/$src.o" ] || [ "$HERE/wino_forms.h" -nt "$OBJ/$src.o" ] || [ "$ROOT/include/bsvd_hip.h" -nt "$OBJ/$src.o" ] || \
      [ "$(cat "$OBJ/$src.flags" 2>/dev/null)" != "$FLAGS" ]; then
@@ -23,5 +27,6 @@ for src in conv3x3_mfma conv3x3_wino conv3x3_winox conv3x3_edge_f32 bsvd_abi; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$OBJ/conv3x3_mfma.o" "$OBJ/conv3x3_wino.o" "$OBJ/conv3x3_winox.o" "$OBJ/conv3x3_edge_f32.o" "$OBJ/bsvd_abi.o" -o "$OUT"
+OBJS=""; for src in $SRCS; do OBJS="$OBJS $OBJ/$src.o"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC $OBJS -o "$OUT"
 echo "built $OUT"

@@ -301,9 +301,14 @@ struct ChunkSrc {          // wave-uniform description of one 16-channel chunk's
 #ifndef BSVD_TUNE_FILL
 #define BSVD_TUNE_FILL 1           // 1: the whole LDS patch of a prologue / single-buffer refill in flight at once
 #endif
-template <class C, int PREC>
+#ifndef BSVD_TUNE_FOLD8_OCC
+#define BSVD_TUNE_FOLD8_OCC 3      // waves/SIMD of the split-fp16 fold-8 instantiation (c32-sized networks): 3 = 168 VGPRs + a 20-byte spill in the
+                                   // chunk loop's preheader (outside the taps), 2 = no spill
+#endif
+template <class C, int PREC, bool MIXF = false>
 constexpr int occ_of()
 {
+    if (MIXF && PREC == 1 && C::OCC > BSVD_TUNE_FOLD8_OCC) return BSVD_TUNE_FOLD8_OCC;
     // exact-fp32 stride 2 (single patch buffer): the refill holds the whole 17x33 patch in registers (72 VGPRs) -> 2 waves/SIMD
     if (C::STRIDE == 2 && PREC == 0 && C::OCC > BSVD_TUNE_S2F32_OCC) return BSVD_TUNE_S2F32_OCC;
     // split-fp16 single-buffer tile with the odd chunk of every 128-byte line held in registers (72 VGPRs): 2 waves/SIMD
@@ -346,12 +351,13 @@ __device__ __forceinline__ void tl_stamp(int slot, int k)
 // (K = 9 taps x 4 channels, padded to 48) straight into the LDS patch buffers, a pair of 16-channel chunks at a time, and
 // never reads an NHWC input tensor.  See head_pair below.
 template <class C, bool FAST, int PREC, bool MIXF = false, bool HEADF = false>
-__global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const ConvParams p)
+__global__ __launch_bounds__(256, (occ_of<C, PREC, MIXF>())) void conv3x3_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *const patch_buf = smem;                              // 2 x PATCH_FLOATS
 
     TL(0);
+    if constexpr (PREC == 1) fp16_saturate_on();      // MODE.FP16_OVFL (bsvd_internal.h): every fp16 conversion of the split mode saturates
     if (BSVD_TUNE_PRIO == 2) __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -564,7 +570,9 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
             // G slices in flight at once, then published.  Everything at once where the registers are there (prologue of
             // the double-buffered tiles, exact-fp32 stride 2 at 2 waves/SIMD); the split-fp16 stride-2 tile stays at 3
             // waves/SIMD and takes BSVD_TUNE_S2_GROUP slices per round trip.
-            constexpr int G = (BSVD_TUNE_FILL && (C::DBUF || PREC == 0)) ? C::NSLICE : BSVD_TUNE_S2_GROUP;
+            // (the fold-8 instantiation issues TWO masked loads per item of its mixed chunk: half the slices per round trip, or the
+            //  prologue spills 20 bytes of scratch)
+            constexpr int G = (BSVD_TUNE_FILL && (C::DBUF || PREC == 0)) ? (MIX ? (C::NSLICE + 1) / 2 : C::NSLICE) : BSVD_TUNE_S2_GROUP;
 #pragma unroll
             for (int g0 = 0; g0 < C::NSLICE; g0 += G) {
                 f32x4 v[G][C::P];
@@ -1031,27 +1039,32 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
     }
     if (BSVD_TUNE_PRIO == 1 || BSVD_TUNE_PRIO == 2) __builtin_amdgcn_s_setprio(2);
     if (BSVD_TUNE_PRIO == 3) __builtin_amdgcn_s_setprio(0);
-    // ---- epilogue.  Lane (li, lh) holds pixel li of the 2 x 16 pixel block of MFMA tile mt (row li>>4, column li&15)
-    //      and, per (mt, nt), two groups of 8 consecutive output channels: registers 8h..8h+7 = channels 8*(2h + lh)..+7
+    // The epilogue's lane-derived values come from a FRESH lane id (v_mbcnt, opaque to the optimiser) instead of the kernel entry's
+    // threadIdx: carried through the K loop they cost the 168-register tiles a 12-16 byte scratch spill (r04 kernel_resources).
+    int elane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(elane));
+    const int eli = elane & 31, elh = elane >> 5;
+    // ---- epilogue.  Lane (eli, elh) holds pixel eli of the 2 x 16 pixel block of MFMA tile mt (row eli>>4, column eli&15)
+    //      and, per (mt, nt), two groups of 8 consecutive output channels: registers 8h..8h+7 = channels 8*(2h + elh)..+7
     //      of the 32-channel tile.
     //      exact fp32 : stored straight from registers, two 16-byte pieces per group (was 16 scalar stores per tile).
     //      split16    : one pixel's 32 channels are 128 contiguous bytes and only ADJACENT lanes coalesce, so the tile is
     //                   transposed through a wave-private LDS scratch ([32 px][32 ch + 4 pad] floats, four ds_write_b128
-    //                   per lane; the patch buffers are free after the last chunk's barrier) and 4 adjacent lanes finish
+    //                   per elane; the patch buffers are free after the last chunk's barrier) and 4 adjacent lanes finish
     //                   the 4 x 8 channels of one pixel.  (Register-direct stores were tried here too: 4x the write
     //                   transactions, 3-11 % slower on the 64-channel and stride-2 layers.)
     //      Everything read from global memory is requested ahead of its use (bias once per tile, the PixelShuffle skip
     //      operand one item ahead), and the item loop is specialised at compile time on (epilogue, activation): at 2-3
     //      waves/SIMD its VALU work is not hidden behind other waves' MFMAs.
     if constexpr (PREC == 1 && C::NT == 1) {
-        // network exit in split mode: channels 0..7 of the single 32-channel tile sit in registers 0..7 of lane half 0;
+        // network exit in split mode: channels 0..7 of the single 32-channel tile sit in registers 0..7 of elane half 0;
         // the y_planar_ch live ones go out as planar fp32 [frames][ch][H][W] with the residual (DenBlock.none_minus,
         // bsvd_arch.py:408-414) and the callers' clamp (validation_seq_infer.py:24) fused.  32 lanes = 2 rows x 16
         // consecutive pixels: 64-byte runs per channel.
         if (p.y_planar_ch > 0) {
-            if (lh == 0 && n0 == 0) {
+            if (elh == 0 && n0 == 0) {
                 const int64_t plane = (int64_t)p.Ho * p.Wo;
-                // the residual base of every pixel of this lane FIRST (split16: channels 0..3 are one 8-byte hi and one 8-byte lo piece): read at
+                // the residual base of every pixel of this elane FIRST (split16: channels 0..3 are one 8-byte hi and one 8-byte lo piece): read at
                 // the point of use, between stores the compiler must assume alias them, the tile's bases were C::MT x channels dependent round trips
                 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
                 [[maybe_unused]] f16x4_t bh[C::MT], bl[C::MT];
@@ -1059,7 +1072,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 if (split_base) {
 #pragma unroll
                     for (int mt = 0; mt < C::MT; ++mt) {
-                        const int oy = oy0 + 2 * C::MT * wm + 2 * mt + (li >> 4), ox = ox0 + (li & 15);
+                        const int oy = oy0 + 2 * C::MT * wm + 2 * mt + (eli >> 4), ox = ox0 + (eli & 15);
                         bh[mt] = bl[mt] = f16x4_t{0, 0, 0, 0};
                         if (oy >= p.Ho || ox >= p.Wo) continue;
                         const _Float16 *e = reinterpret_cast<const _Float16 *>(p.extra + (int64_t)f * p.extra_fs + ((int64_t)oy * p.Wo + ox) * p.extra_ps);
@@ -1069,7 +1082,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 }
 #pragma unroll
                 for (int mt = 0; mt < C::MT; ++mt) {
-                    const int oy = oy0 + 2 * C::MT * wm + 2 * mt + (li >> 4), ox = ox0 + (li & 15);
+                    const int oy = oy0 + 2 * C::MT * wm + 2 * mt + (eli >> 4), ox = ox0 + (eli & 15);
                     if (oy >= p.Ho || ox >= p.Wo) continue;
                     const int64_t opix = (int64_t)oy * p.Wo + ox;
 #pragma unroll
@@ -1094,14 +1107,14 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         }
     }
     const int Cq = p.Cout >> 2;   // PS_ADD: channels of the shuffled output
-    constexpr int NB = PREC == 1 ? 1 : 2;                    // 8-channel groups per (lane, nt) whose bias is kept
-    const int q = lane & 3;
+    constexpr int NB = PREC == 1 ? 1 : 2;                    // 8-channel groups per (elane, nt) whose bias is kept
+    const int q = elane & 3;
     f32x4 bq[C::NT][NB][2];
 #pragma unroll
     for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
         for (int h = 0; h < NB; ++h) {
-            const int n8 = n0 + wn * (C::NT * 32) + nt * 32 + (PREC == 1 ? 8 * q : 8 * (2 * h + lh));
+            const int n8 = n0 + wn * (C::NT * 32) + nt * 32 + (PREC == 1 ? 8 * q : 8 * (2 * h + elh));
             bq[nt][h][0] = bq[nt][h][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.bias && n8 < p.Cout) {
                 bq[nt][h][0] = *reinterpret_cast<const f32x4 *>(p.bias + n8);
@@ -1113,20 +1126,20 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         constexpr int EPI = decltype(epi_c)::value, ACT = decltype(act_c)::value;
         constexpr bool PSF = decltype(psf_c)::value;      // PixelShuffle items with wave-uniform sub-pixel / channel base
         struct Item { bool live; int64_t opix; int n8, c8; float *dst; const float *esrc; };
-        // PLAIN / RESID: everything that depends on the lane is computed once; an item only adds compile-time multiples of
+        // PLAIN / RESID: everything that depends on the elane is computed once; an item only adds compile-time multiples of
         // the (wave-uniform) row stride -- every instruction of a finishing wave waits for a gap between the co-resident
         // wave's MFMAs, so per-item 64-bit address arithmetic was a measurable part of the epilogue
-        const int l_ox = PREC == 1 ? ox0 + (lane >> 2) : ox0 + (li & 15);
-        const int l_oy = oy0 + 2 * C::MT * wm + (PREC == 1 ? 0 : (li >> 4));
-        const int l_ch = n0 + wn * (C::NT * 32) + (PREC == 1 ? 8 * q : 8 * lh);
+        const int l_ox = PREC == 1 ? ox0 + (elane >> 2) : ox0 + (eli & 15);
+        const int l_oy = oy0 + 2 * C::MT * wm + (PREC == 1 ? 0 : (eli >> 4));
+        const int l_ch = n0 + wn * (C::NT * 32) + (PREC == 1 ? 8 * q : 8 * elh);
         const int64_t l_pix = (int64_t)l_oy * p.Wo + l_ox;
         const int64_t rowstride = (int64_t)p.Wo * p.Cout;
         float *const l_base = p.y + (int64_t)f * p.y_fs + l_pix * p.Cout +
                               (PREC == 1 ? (l_ch >> 4) * 16 + ((l_ch >> 3) & 1) * 4 : l_ch);
         // PixelShuffle items of the split mode, Cq % 32 == 0 (every c64 / c32-sized network): a 32-channel MFMA tile lies inside
         // ONE sub-pixel plane, so the sub-pixel, the channel base and the row are wave-uniform and an item's address is
-        // (lane part, computed once) + (scalar part).  The generic form below divides by Cq and does 64-bit multiplies per
-        // lane and item: 150-230 instructions per item against 60 here -- each of them waits for a gap between the
+        // (elane part, computed once) + (scalar part).  The generic form below divides by Cq and does 64-bit multiplies per
+        // elane and item: 150-230 instructions per item against 60 here -- each of them waits for a gap between the
         // co-resident wave's MFMAs (the 128->256 layer ran 12 % below the temporal-fusion layers of the same shape).
         [[maybe_unused]] int ps_sub0 = 0, ps_rem0 = 0, ps_r[C::NT] = {}, ps_sub[C::NT] = {};
         [[maybe_unused]] float *ps_ybase = nullptr;
@@ -1134,7 +1147,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
         if constexpr (PSF) {
             ps_sub0 = n0 / Cq;
             ps_rem0 = n0 - ps_sub0 * Cq;
-            const int lq = (q >> 1) * 16 + (q & 1) * 4;              // this lane's 8-channel piece inside a 32-channel tile
+            const int lq = (q >> 1) * 16 + (q & 1) * 4;              // this elane's 8-channel piece inside a 32-channel tile
             const int64_t lpix = (int64_t)(2 * l_oy) * (2 * p.Wo) + 2 * l_ox;
             ps_ybase = p.y + (int64_t)f * p.y_fs + lpix * Cq + lq;
             ps_ebase = p.extra ? p.extra + (int64_t)f * p.extra_fs + lpix * p.extra_ps + lq : nullptr;
@@ -1167,7 +1180,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 }
             }
             if constexpr (EPI != BSVD_EPI_PS_ADD) {
-                const int row = 2 * mt + (PREC == 1 ? sidx : 0);             // rows below the lane's base row
+                const int row = 2 * mt + (PREC == 1 ? sidx : 0);             // rows below the elane's base row
                 const int chadd = nt * 32 + (PREC == 1 ? 0 : 16 * sidx);     // channels (= floats in both layouts) above l_ch
                 t.n8 = t.c8 = l_ch + chadd;
                 t.live = l_oy + row < p.Ho && l_ox < p.Wo && t.n8 < p.Cout;
@@ -1176,14 +1189,14 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 return t;
             }
             if constexpr (PREC == 1) {       // s = which 16 of the tile's 32 pixels; 4 adjacent lanes share a pixel
-                const int m = (lane + 64 * sidx) >> 2;
+                const int m = (elane + 64 * sidx) >> 2;
                 oy = oy0 + 2 * C::MT * wm + 2 * mt + (m >> 4);
                 ox = ox0 + (m & 15);
                 t.n8 = n0 + wn * (C::NT * 32) + nt * 32 + 8 * q;
-            } else {                         // s = h: which of the lane's two channel groups
-                oy = oy0 + 2 * C::MT * wm + 2 * mt + (li >> 4);
-                ox = ox0 + (li & 15);
-                t.n8 = n0 + wn * (C::NT * 32) + nt * 32 + 8 * (2 * sidx + lh);
+            } else {                         // s = h: which of the elane's two channel groups
+                oy = oy0 + 2 * C::MT * wm + 2 * mt + (eli >> 4);
+                ox = ox0 + (eli & 15);
+                t.n8 = n0 + wn * (C::NT * 32) + nt * 32 + 8 * (2 * sidx + elh);
             }
             t.live = oy < p.Ho && ox < p.Wo && t.n8 < p.Cout;
             if constexpr (EPI == BSVD_EPI_PS_ADD) {
@@ -1242,12 +1255,12 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 // (r03: requesting both items of tile k, staging tile k+1 behind those reads with no wait in between -- a wave's LDS
                 //  instructions execute in order -- and only then converting moved nothing, 19.65 vs 19.67 ms: the timeline build
                 //  (tools/timeline.py, -DBSVD_TIMELINE=2) puts 80 % of the epilogue into the convert + store part, 20 % into LDS.)
-                auto stage = [&](int smt, int snt) {      // row = pixel li, 8 consecutive channels per write
+                auto stage = [&](int smt, int snt) {      // row = pixel eli, 8 consecutive channels per write
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        float *w = sc + li * 36 + 8 * (2 * h + lh);
+                        float *w = sc + eli * 36 + 8 * (2 * h + elh);
                         const f32x16 &a = acc[smt][snt];
                         *reinterpret_cast<f32x4 *>(w) = f32x4{a[8 * h], a[8 * h + 1], a[8 * h + 2], a[8 * h + 3]};
                         *reinterpret_cast<f32x4 *>(w + 4) = f32x4{a[8 * h + 4], a[8 * h + 5], a[8 * h + 6], a[8 * h + 7]};
@@ -1260,7 +1273,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
                 TLP_MARK(0);
-                const int m = (lane + 64 * sidx) >> 2;
+                const int m = (elane + 64 * sidx) >> 2;
                 const f32x4 v0 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8);
                 const f32x4 v1 = *reinterpret_cast<const f32x4 *>(sc + m * 36 + q * 8 + 4);
                 TLP_WAIT_MARK(1, v0, v1);
@@ -1298,7 +1311,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                 }
                 if constexpr (PREC == 1) {
                     float *dst = t.dst;
-                    constexpr bool bounded = ACT == BSVD_ACT_RELU6 && EPI == BSVD_EPI_PLAIN;
+                    constexpr bool bounded = (ACT == BSVD_ACT_RELU6 && EPI == BSVD_EPI_PLAIN) || !BSVD_EPI_CLAMP;
                     f16x8 hi, lo;
                     // (lo = fp16(v - hi) as inline-asm v_fma_mix{lo,hi}_f16 was tried in r03: 12 instead of 20 conversion instructions
                     //  per 8 channels, bit-identical, 64-channel tile 6.22 -> 6.18 ms per clip but the fat tile 19.74 -> 19.87 -- and an
@@ -1312,7 +1325,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC>())) void conv3x3_kernel(const
                     if constexpr ((BSVD_ABL & 32) != 0) {      // timing only: conversion kept alive, stores never executed
                         if (p.Cout < 0) { *reinterpret_cast<f32x4 *>(dst) = __builtin_bit_cast(f32x4, hi); *reinterpret_cast<f32x4 *>(dst + 8) = __builtin_bit_cast(f32x4, lo); }
                     } else if constexpr ((BSVD_ABL & 128) != 0) {  // timing only: the same bytes as fully coalesced 2-KB runs per wave and item
-                        float *d2 = p.y + (int64_t)f * 0 + ((int64_t)((blockIdx.x % (gridDim.x - gridDim.x / 16)) * 4 + wid) * NITEM + i) * 512 + lane * 8;   // (stays inside the tensor: edge tiles fold back)
+                        float *d2 = p.y + (int64_t)f * 0 + ((int64_t)((blockIdx.x % (gridDim.x - gridDim.x / 16)) * 4 + wid) * NITEM + i) * 512 + elane * 8;   // (stays inside the tensor: edge tiles fold back)
                         *reinterpret_cast<f32x4 *>(d2) = __builtin_bit_cast(f32x4, hi); *reinterpret_cast<f32x4 *>(d2 + 4) = __builtin_bit_cast(f32x4, lo);
                     } else if constexpr ((BSVD_ABL & 64) != 0) {   // timing only: stores kept, no split conversion
                         *reinterpret_cast<f32x4 *>(dst) = f32x4{v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4 *>(dst + 8) = f32x4{v[4], v[5], v[6], v[7]};
@@ -1448,9 +1461,9 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
             return launch_cfg<ConvCfg<2, 1, 4, 1, 1, 3>, true, 1>(p, stream, name, name_len);
         }
         if (stride == 2) {
-            if (BSVD_TUNE_S2_SPLIT == 1) return launch_cfg<ConvCfg<1, 2, 2, 2, 2, 3, true>, true, 1>(p, stream, name, name_len);
-            if (BSVD_TUNE_S2_DBUF == 1) return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, true>, true, 1>(p, stream, name, name_len);
-            return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, false>, true, 1>(p, stream, name, name_len);
+            if constexpr (BSVD_TUNE_S2_SPLIT == 1) return launch_cfg<ConvCfg<1, 2, 2, 2, 2, 3, true>, true, 1>(p, stream, name, name_len);
+            else if constexpr (BSVD_TUNE_S2_DBUF == 1) return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, true>, true, 1>(p, stream, name, name_len);
+            else return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, false>, true, 1>(p, stream, name, name_len);
         }
         // The fat tiles run one workgroup per CU, so they need a grid of several rounds of 256; small launches
         // (streaming mode: one frame per launch) keep the 64x64 tiles at 3 workgroups per CU.
@@ -1465,11 +1478,11 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
                                    // weight bytes per MFMA, twice the pixel-fragment reads)
 #endif
             if (fat_wide >= fat_min) {
-                if (BSVD_TUNE_FAT_SHAPE == 1) return launch_cfg<ConvCfg<8, 1, 1, 4, 1, 3>, true, 1>(p, stream, name, name_len);
-                return launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
+                if constexpr (BSVD_TUNE_FAT_SHAPE == 1) return launch_cfg<ConvCfg<8, 1, 1, 4, 1, 3>, true, 1>(p, stream, name, name_len);
+                else return launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
             }
-            if (BSVD_TUNE_THIN_ALT) return launch_cfg<ConvCfg<4, 1, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
-            return launch_cfg<ConvCfg<2, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
+            if constexpr (BSVD_TUNE_THIN_ALT != 0) return launch_cfg<ConvCfg<4, 1, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
+            else return launch_cfg<ConvCfg<2, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
         }
         if (p.fold == 8) return launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1, true>(p, stream, name, name_len);   // c32-sized nets
 #ifndef BSVD_TUNE_NARROW_ALT
@@ -1478,8 +1491,8 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
                                    // L1: ~42 B/clk/CU of its 64), twice the pixel-fragment reads -- a loss with the padded LDS layout (r01: "no gain"),
                                    // a 7 % gain with the conflict-free quad-planar one (r03: 6.42 -> 5.94 ms per clip on one box)
 #endif
-        if (BSVD_TUNE_NARROW_ALT) return launch_cfg<ConvCfg<4, 1, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
-        return launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1>(p, stream, name, name_len);   // (512-px fat tiles were tried: 9.6 vs 6.8 ms)
+        if constexpr (BSVD_TUNE_NARROW_ALT != 0) return launch_cfg<ConvCfg<4, 1, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
+        else return launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1>(p, stream, name, name_len);   // (512-px fat tiles were tried: 9.6 vs 6.8 ms)
     }
     // exact fp32.  Cout <= 64 (the 540x960-level layers of bsvd_c64): 256 px x 64 ch tiles; wider layers: 128 px x 128 ch.
     // Stride 2 always takes the 128 x 128 tile with a single patch buffer (its 17x33 input patch is what bounds LDS).

@@ -26,6 +26,9 @@
 //     straight from L2 to VGPRs two steps ahead in a 3-deep register ring, layout [chunk][xi][ky][hi|lo][h][Cout][8 fp16].
 // Epilogue: AT in fp32 on the accumulators, then the direct kernel's split epilogue per output column j < M (wave-private LDS
 // transposition so that 4 adjacent lanes write one pixel's 128 contiguous bytes; bias, activation, PixelShuffle + skip add).
+// MEASUREMENT VARIANT: compiled into measurement builds only (-DBSVD_MEASURE, tools/build_measure.sh); the product library
+// does not contain this kernel.  Kept as the record of the first design of DESIGN.md 4.1d (wino_m 12 / 14).
+#ifdef BSVD_MEASURE
 #include <stdio.h>
 #include <type_traits>
 #include "bsvd_internal.h"
@@ -449,21 +452,6 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const ConvParams p)
 }
 
 // Can this layer run on the Winograd kernel?  (nullptr = yes, else the reason)
-const char *wino_unsupported(const ConvParams &p, int stride)
-{
-    if (p.prec != 1) return "dtype must be BSVD_F16X3";
-    if (p.wino_m != 2 && p.wino_m != 4 && p.wino_m != 6 && p.wino_m != 12 && p.wino_m != 14 && p.wino_m != 22 && p.wino_m != 32 && p.wino_m != 42 && p.wino_m != 52 && p.wino_m != 62 && p.wino_m != 36 && p.wino_m != 46) return "wino_m must be 2, 4 or 6 (12 | 14: the all-positions-per-wave kernel; 22 | 32 | 42: F(2,3) on 4-wave workgroups / always on the half-height tile / never on it)";
-    if (stride != 1) return "stride must be 1";
-    if (p.epilogue == BSVD_EPI_RESID || p.y_planar_ch > 0 || p.head_w) return "only PLAIN / PS_ADD NHWC layers";
-    if ((p.fold & 15) != 0) return "fold must be a multiple of 16";
-    if (!p.vec_ok) return "16-byte aligned x / halo pointers and strides";
-    if ((p.Cout & 31) != 0) return "Cout must be a multiple of 32";
-    if (p.epilogue == BSVD_EPI_PS_ADD && (p.extra != nullptr && p.extra_cs != 1)) return "PS_ADD skip tensor must be split16 NHWC (extra_cstride 1)";
-    if ((int64_t)p.H * p.W * p.Cin * 4 >= 0x7fffffffLL) return "frame >= 2 GiB";
-    if ((int64_t)p.Cin * 3 * (p.wino_m % 10 + 2) * p.Cout * 4 >= 0x7fffffffLL) return "packed weights >= 2 GiB";
-    return nullptr;
-}
-
 template <int M>
 static int launch_wino_m(const ConvParams &pin, hipStream_t stream, char *name, int name_len)
 {
@@ -492,3 +480,4 @@ int launch_wino(const ConvParams &p, hipStream_t stream, char *name, int name_le
 }
 
 }  // namespace bsvd
+#endif  // BSVD_MEASURE

@@ -162,10 +162,17 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned &hp, uns
     hp = __builtin_bit_cast(unsigned, hv);
 #if BSVD_WX_MIXASM
     // both residuals straight from the PACKED hi pair (op_sel picks its halves): 3 instructions per channel pair.  Left to itself hipcc converts
-    // each channel a second time (v_cvt_f16_f32) to have the fma_mix source in a low half: 5.  Same arithmetic, same bits.  The results go to
-    // ds_write only (hardware-interlocked; no software wait states involved)
-    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hp), "s"(k.mone), "v"(v0));
-    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hp), "s"(k.mone), "v"(v1));
+    // each channel a second time (v_cvt_f16_f32) to have the fma_mix source in a low half: 5.  Same arithmetic, same bits.
+    // ONE asm block: the two partial-register writes (dst_sel) are invisible to the compiler's hazard recognizer, so the block itself ends with
+    // the wait state a VALU reader of `lp` would need on gfx950 -- today the only consumer is ds_write (hardware-interlocked), and whatever
+    // a later edit or another scheduler puts behind the block is safe too.  BSVD_WX_MIXASM on == off bit for bit:
+    // tests/measure_driver.py (`mixasm`).
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+#if BSVD_WX_MIXASM != 2      // (2: without the trailing wait state -- A/B of its cost only)
+        "\n\ts_nop 0"
+#endif
+        : "=&v"(lp) : "v"(hp), "s"(k.mone), "v"(v0), "v"(v1));
 #else
     const f16x2_t lv = {(_Float16)__builtin_fmaf((float)hv[0], k.mone, v0), (_Float16)__builtin_fmaf((float)hv[1], k.mone, v1)};
     lp = __builtin_bit_cast(unsigned, lv);
@@ -220,6 +227,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
 
     [[maybe_unused]] unsigned long long tl_acc[7] = {0, 0, 0, 0, 0, 0, 0};
     [[maybe_unused]] const unsigned long long tl_start = WXT_NOW();
+    fp16_saturate_on();        // MODE.FP16_OVFL: see bsvd_internal.h (the transformed values reach 2x .. 4.7x the activation range)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -910,7 +918,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
                         dst = p.y + (int64_t)f * p.y_fs + ((int64_t)oy * p.Wo + ox) * p.Cout + coff16(n8);
                     }
                     if (live) {
-                        constexpr bool bounded = ACT == BSVD_ACT_RELU6 && EPI == BSVD_EPI_PLAIN;
+                        constexpr bool bounded = (ACT == BSVD_ACT_RELU6 && EPI == BSVD_EPI_PLAIN) || !BSVD_EPI_CLAMP;
                         f16x8 hi, lo;
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
@@ -975,46 +983,87 @@ static int launch_winox_cfg(const ConvParams &pin, hipStream_t stream, char *nam
     return (int)hipGetLastError();
 }
 
+// Which wino_m codes this build runs.  Product: 2 / 6 (F(2,3) / F(6,3), each picking the half-height tile for grids that do not fill the
+// chip) and 42 / 46 (the same forms, never on the half-height tile: launches that share the chip with another graph branch).  A measurement
+// build (-DBSVD_MEASURE, tools/build_measure.sh -> build/measure/libbsvd_hip.so; never the product library) adds F(4,3), the 4-wave
+// workgroup, the forced tiles, the persistent form and the all-positions-per-wave kernel of conv3x3_wino.hip -- same arithmetic per form,
+// kept for the records in DESIGN.md 4.1d and for tests/measure_driver.py.
+static bool wino_code_known(int m)
+{
+    if (m == 2 || m == 6 || m == 42 || m == 46) return true;
+#ifdef BSVD_MEASURE
+    if (m == 4 || m == 12 || m == 14 || m == 22 || m == 32 || m == 36 || m == 52 || m == 62) return true;
+#endif
+    return false;
+}
+
+const char *wino_unsupported(const ConvParams &p, int stride)
+{
+    if (p.prec != 1) return "dtype must be BSVD_F16X3";
+    if (!wino_code_known(p.wino_m))
+#ifdef BSVD_MEASURE
+        return "wino_m must be 2 or 6 (42 / 46: never the half-height tile; measurement build: 4, 12, 14, 22, 32, 36, 52, 62)";
+#else
+        return "wino_m must be 2 or 6 (42 / 46: the same forms, never on the half-height tile); the other codes exist in measurement builds (-DBSVD_MEASURE) only";
+#endif
+    if (stride != 1) return "stride must be 1";
+    if (p.epilogue == BSVD_EPI_RESID || p.y_planar_ch > 0 || p.head_w) return "only PLAIN / PS_ADD NHWC layers";
+    if ((p.fold & 15) != 0) return "fold must be a multiple of 16";
+    if (!p.vec_ok) return "16-byte aligned x / halo pointers and strides";
+    if ((p.Cout & 31) != 0) return "Cout must be a multiple of 32";
+    if (p.epilogue == BSVD_EPI_PS_ADD && (p.extra != nullptr && p.extra_cs != 1)) return "PS_ADD skip tensor must be split16 NHWC (extra_cstride 1)";
+    if ((int64_t)p.H * p.W * p.Cin * 4 >= 0x7fffffffLL) return "frame >= 2 GiB";
+    // the halo descriptors are hw * pstride * 4 bytes in 32 bits too: a pstride larger than Cin must not wrap (it would read as zeros)
+    if (p.fold > 0 && p.halo_prev && (int64_t)p.H * p.W * p.halo_prev_ps * 4 >= 0x7fffffffLL) return "halo_prev: H * W * pstride * 4 >= 2 GiB";
+    if (p.fold > 0 && p.halo_next && (int64_t)p.H * p.W * p.halo_next_ps * 4 >= 0x7fffffffLL) return "halo_next: H * W * pstride * 4 >= 2 GiB";
+    if ((int64_t)p.Cin * 3 * (p.wino_m % 10 + 2) * p.Cout * 4 >= 0x7fffffffLL) return "packed weights >= 2 GiB";
+    return nullptr;
+}
+
 int launch_winox(const ConvParams &p, hipStream_t stream, char *name, int name_len)
 {
+    // F(2,3) / F(6,3).  Small grids (single-frame launches of the stream schedules): one 8-wave workgroup per CU, so the launch takes
+    // ceil(workgroups / 256) rounds -- 270 workgroups (256 -> 256 at 135 x 240) cost two full rounds for 1.05 rounds of work.
+    // The half-height tile has twice the workgroups and computes every output with the same instruction sequence (bit-identical:
+    // stream == clip stays bitwise), at ~0.87 of the full tile's efficiency (10 patch rows per 8, prologue / epilogue per tile).
+    // 42 / 46: never the half-height tile -- launches that share the chip with another graph branch (the lagged two-chain stream
+    // step): idle CUs are not idle there.
+    auto fill = [](int64_t n) { return (double)n / (double)(((n + BSVD_CUS - 1) / BSVD_CUS) * BSVD_CUS); };
     switch (p.wino_m) {
+    case 2:
+    case 42: {
+        using C4 = XCfg<2, 2, 2, 4>;
+        const int64_t per_row = (int64_t)p.frames * ((p.Wo + C4::TWPX - 1) / C4::TWPX) * ((p.Cout + C4::BN - 1) / C4::BN);
+        const int64_t n4 = per_row * ((p.Ho + 15) / 16), n2 = per_row * ((p.Ho + 7) / 8);
+        if (p.wino_m == 2 && n4 < 8 * BSVD_CUS && 0.87 * fill(n2) > fill(n4)) return launch_winox_cfg<2, 2, 2, 2>(p, stream, name, name_len);
+#ifdef BSVD_MEASURE
+        // (large grids as 256 persistent workgroups, the transform pipeline running across tile boundaries: built, bit-identical, 6-13 %
+        //  slower, DESIGN 4.1d -- only a measurement build with -DBSVD_WX_PERSIST_MIN=<tiles per CU> ever selects it)
+        if (n4 >= (int64_t)BSVD_WX_PERSIST_MIN * BSVD_CUS) return launch_winox_cfg<2, 2, 2, 4, true>(p, stream, name, name_len);
+#endif
+        return launch_winox_cfg<2, 2, 2>(p, stream, name, name_len);
+    }
+    case 46: return launch_winox_cfg<6, 1, 2>(p, stream, name, name_len);
+    case 6: {
+        using C4 = XCfg<6, 1, 2, 4>;
+        const int64_t per_row = (int64_t)p.frames * ((p.Wo + C4::TWPX - 1) / C4::TWPX) * ((p.Cout + C4::BN - 1) / C4::BN);
+        const int64_t n4 = per_row * ((p.Ho + 15) / 16), n2 = per_row * ((p.Ho + 7) / 8);
+        if (n4 < 8 * BSVD_CUS && 0.87 * fill(n2) > fill(n4)) return launch_winox_cfg<6, 1, 2, 2>(p, stream, name, name_len);
+        return launch_winox_cfg<6, 1, 2>(p, stream, name, name_len);
+    }
+#ifdef BSVD_MEASURE
     case 22: return launch_winox_cfg<2, 1, 2>(p, stream, name, name_len);     // 4-wave workgroups, two per CU
-    case 32: return launch_winox_cfg<2, 2, 2, 2>(p, stream, name, name_len);  // the half-height tile whatever the grid (tests, A/B)
+    case 32: return launch_winox_cfg<2, 2, 2, 2>(p, stream, name, name_len);  // the half-height tile whatever the grid
     case 52: return launch_winox_cfg<2, 2, 2>(p, stream, name, name_len);     // one tile per workgroup whatever the grid (A/B of the persistent form)
-    case 62: {               // the persistent form whatever the grid (tests, records): small grids on 8 workgroups, so that every one walks several tiles
+    case 62: {               // the persistent form whatever the grid: small grids on 8 workgroups, so that every one walks several tiles
         using C4 = XCfg<2, 2, 2, 4>;
         const int64_t n4 = (int64_t)p.frames * ((p.Wo + C4::TWPX - 1) / C4::TWPX) * ((p.Cout + C4::BN - 1) / C4::BN) * ((p.Ho + 15) / 16);
         return launch_winox_cfg<2, 2, 2, 4, true>(p, stream, name, name_len, n4 < 2 * BSVD_CUS ? 8 : BSVD_CUS);
     }
-    case 2:
-    case 42: {                // 42: never the half-height tile -- launches that share the chip with another graph branch (the lagged two-chain
-                              // stream step): idle CUs are not idle there
-        // Small grids (single-frame launches of the stream schedules): one 8-wave workgroup per CU, so the launch takes
-        // ceil(workgroups / 256) rounds -- 270 workgroups (256 -> 256 at 135 x 240) cost two full rounds for 1.05 rounds of work.
-        // The half-height tile has twice the workgroups and computes every output with the same instruction sequence (bit-identical:
-        // stream == clip stays bitwise), at ~0.87 of the full tile's efficiency (10 patch rows per 8, prologue / epilogue per tile).
-        // Large grids: 256 persistent workgroups, each walking its share of the tiles with the transform pipeline running across tile
-        // boundaries (a tile's prologue -- first loads, first transform, 10 of its 70-120 thousand cycles -- hides under its
-        // predecessor's last MFMA steps).  Same instruction sequence per output again.
-        using C4 = XCfg<2, 2, 2, 4>;
-        const int64_t per_row = (int64_t)p.frames * ((p.Wo + C4::TWPX - 1) / C4::TWPX) * ((p.Cout + C4::BN - 1) / C4::BN);
-        const int64_t n4 = per_row * ((p.Ho + 15) / 16), n2 = per_row * ((p.Ho + 7) / 8);
-        auto fill = [](int64_t n) { return (double)n / (double)(((n + BSVD_CUS - 1) / BSVD_CUS) * BSVD_CUS); };
-        if (p.wino_m == 2 && n4 < 8 * BSVD_CUS && 0.87 * fill(n2) > fill(n4)) return launch_winox_cfg<2, 2, 2, 2>(p, stream, name, name_len);
-        if (n4 >= BSVD_WX_PERSIST_MIN * BSVD_CUS) return launch_winox_cfg<2, 2, 2, 4, true>(p, stream, name, name_len);
-        return launch_winox_cfg<2, 2, 2>(p, stream, name, name_len);
-    }
     case 4: return launch_winox_cfg<4, 2, 1>(p, stream, name, name_len);
-    case 36: return launch_winox_cfg<6, 1, 2, 2>(p, stream, name, name_len);   // F(6,3) on the half-height tile whatever the grid (tests, A/B)
-    case 46: return launch_winox_cfg<6, 1, 2>(p, stream, name, name_len);      // ... never on it (launches that share the chip, see 42)
-    default: {                // F(6,3): the same choice between the 16- and the 8-row tile for grids that do not fill the chip
-        using C4 = XCfg<6, 1, 2, 4>;
-        const int64_t per_row = (int64_t)p.frames * ((p.Wo + C4::TWPX - 1) / C4::TWPX) * ((p.Cout + C4::BN - 1) / C4::BN);
-        const int64_t n4 = per_row * ((p.Ho + 15) / 16), n2 = per_row * ((p.Ho + 7) / 8);
-        auto fill = [](int64_t n) { return (double)n / (double)(((n + BSVD_CUS - 1) / BSVD_CUS) * BSVD_CUS); };
-        if (n4 < 8 * BSVD_CUS && 0.87 * fill(n2) > fill(n4)) return launch_winox_cfg<6, 1, 2, 2>(p, stream, name, name_len);
-        return launch_winox_cfg<6, 1, 2>(p, stream, name, name_len);
-    }
+    case 36: return launch_winox_cfg<6, 1, 2, 2>(p, stream, name, name_len);   // F(6,3) on the half-height tile whatever the grid
+#endif
+    default: set_error("bsvd_conv3x3: wino_m %d is not in this build", p.wino_m); return -19;
     }
 }
 

@@ -13,7 +13,7 @@
 // which checks the matrices against the defining identity and the hand-factored transforms below against the matrices.
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define BSVD_HD __host__ __device__ __forceinline__
 #else
 #define BSVD_HD inline

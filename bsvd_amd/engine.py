@@ -35,11 +35,31 @@ def head_fusable(inc0, inc3, precision):
             and not inc3.tsm and inc3.epilogue == EPI_PLAIN and inc0.act == inc3.act)
 
 
-# Forms of the wide layers PackedNet accepts.  For users: "direct", "wino2" (default of arch.BSVD), "wino4", "wino6", "wino26" (F(2,3) on the
-# 128 -> 128 layers, F(6,3) on the wider ones).  Measurement / test variants of the same arithmetic (bit-identical to their base form): "wino2h" /
-# "wino6h" always the 8-row tile, "wino2n" never the persistent form, "wino2p" always, "wino2s" 4-wave workgroups, "wino2b" / "wino4b" the
-# all-positions-per-wave kernel (conv3x3_wino.hip).
-WIDE_CONV = ("direct", "wino2", "wino4", "wino6", "wino2b", "wino4b", "wino2s", "wino2h", "wino2p", "wino2n", "wino6h", "wino26")
+# Forms of the wide layers: "direct" (3-pass implicit GEMM), "wino2" (1-D Winograd F(2,3) along x; default of arch.BSVD), "wino6" (F(6,3)),
+# "wino26" (F(2,3) on the 128 -> 128 layers, F(6,3) on the wider ones).  That is all the product library contains.
+WIDE_CONV = ("direct", "wino2", "wino6", "wino26")
+# Measurement / test variants of the same arithmetic -- accepted only when the loaded library is a MEASUREMENT build (tools/build_measure.sh,
+# selected with BSVD_HIP_LIB; bsvd_build_info() & BUILD_MEASURE): name -> (F(m,3), BsvdConvArgs.wino_m).  "wino4" F(4,3); "wino2h" / "wino6h"
+# always the 8-row tile; "wino2n" one tile per workgroup whatever the grid, "wino2p" the persistent form; "wino2s" 4-wave workgroups;
+# "wino2b" / "wino4b" the all-positions-per-wave kernel (conv3x3_wino.hip).  DESIGN.md 4.1d records each of them as slower.
+MEASURE_WIDE_CONV = {"wino4": (4, 4), "wino2b": (2, 12), "wino4b": (4, 14), "wino2s": (2, 22), "wino2h": (2, 32), "wino6h": (6, 36),
+                     "wino2n": (2, 52), "wino2p": (2, 62)}
+_FORMS = {"direct": (0, 0), "wino2": (2, 2), "wino6": (6, 6), "wino26": (6, 6)}
+
+# fp16 range of the transformed weights U = G g (bsvd_pack_weights_wino): |U| <= max |w| x the largest |G| row sum of the form
+# (wino_forms.h).  A layer whose bound leaves fp16's range stays on the direct form (PackedNet).
+WINO_G_ROW_SUM = {2: 1.5, 4: 14.0 / 3.0, 6: 2048.0 / 315 + 512.0 / 105 + 128.0 / 35}
+F16_PAIR_LIMIT = 6.0e4          # the same limit arch.BSVD applies to the raw weights (fp16 max 65504)
+
+
+def wide_conv_known(name, lib=None):
+    """Is ``name`` a form this process can run?  Product names always; measurement names only on a measurement library."""
+    if name in WIDE_CONV:
+        return True
+    if name in MEASURE_WIDE_CONV:
+        lib = lib or _lib.load()
+        return bool(lib.bsvd_build_info() & _lib.BUILD_MEASURE)
+    return False
 
 
 WINO_MIN_CIN = 128     # narrowest layer the Winograd form takes (engine.PackedNet(wino_min_cin=...))
@@ -60,17 +80,21 @@ class PackedNet:
 
     def __init__(self, net, state, device, precision="fp32", wide_conv="direct", wino_min_cin=None):
         lib = require_hip()
-        if wide_conv not in WIDE_CONV:
+        if not wide_conv_known(wide_conv, lib):
+            if wide_conv in MEASURE_WIDE_CONV:
+                raise ValueError("wide_conv=%r is a measurement variant: it exists in a -DBSVD_MEASURE build of the library only "
+                                 "(tools/build_measure.sh, BSVD_HIP_LIB=build/measure/libbsvd_hip.so); the product forms are %s"
+                                 % (wide_conv, WIDE_CONV))
             raise ValueError("wide_conv must be one of %s" % (WIDE_CONV,))
         self.device = device
         self.precision = precision
         self.wide_conv = wide_conv
-        # F(m,3) form; the ABI's wino_m + 10 selects the all-positions-per-wave kernel (conv3x3_wino.hip, measurement variant)
-        self.wino_m = {"direct": 0, "wino2": 2, "wino4": 4, "wino6": 6, "wino2b": 2, "wino4b": 4, "wino2s": 2, "wino2h": 2, "wino2p": 2, "wino2n": 2, "wino6h": 6, "wino26": 6}[wide_conv]
-        self.wino_abi = self.wino_m + (10 if wide_conv.endswith("b") else 20 if wide_conv.endswith("s") else 30 if wide_conv.endswith("h") else 60 if wide_conv.endswith("p") else 50 if wide_conv.endswith("n") else 0)
-        self.wino_min_cin = int(os.environ.get("BSVD_WINO_MIN_CIN", WINO_MIN_CIN)) if wino_min_cin is None else int(wino_min_cin)
+        # F(m,3) form and the wino_m code handed to the library
+        self.wino_m, self.wino_abi = _FORMS[wide_conv] if wide_conv in _FORMS else MEASURE_WIDE_CONV[wide_conv]
+        self.wino_min_cin = WINO_MIN_CIN if wino_min_cin is None else int(wino_min_cin)
         self.wino = {}               # {spec.key: transformed pack} of the layers that run on the Winograd kernel
         self.wino_layer_abi = {}     # {spec.key: BsvdConvArgs.wino_m} -- "wino26": F(2,3) for the 128 -> 128 layers, F(6,3) for the wider ones
+        self.wino_range_fallback = []    # eligible layers kept on the direct form because max |G g| would leave fp16's range
         self.tensors = {}
         self.order = {sp.key: i for i, sp in enumerate(net.layers)}      # position in the layer-major walk (tile_order parity)
         edge = set()
@@ -87,11 +111,9 @@ class PackedNet:
                 if tuple(w.shape) != (sp.cout, sp.cin, 3, 3):
                     raise ValueError("%s.weight has shape %s, expected %s" % (sp.key, tuple(w.shape), (sp.cout, sp.cin, 3, 3)))
                 bp = torch.empty(sp.cout_pad, dtype=torch.float32, device=device)
-                if self.wino_m and wino_eligible(sp, precision, self.wino_min_cin):
-                    # (a property of the LAYER, like eligibility itself: every schedule runs the same form per layer)
-                    m, abi = self.wino_m, self.wino_abi
-                    if wide_conv == "wino26" and sp.cin_pad <= 128 and sp.cout_pad <= 128:
-                        m = abi = 2
+                form = self._layer_form(sp, w)
+                if form is not None:
+                    m, abi = form
                     n = lib.bsvd_packed_wino_weight_elems(sp.cin_pad, sp.cout_pad, m)
                     wq = torch.empty(n, dtype=torch.float32, device=device)
                     rc = lib.bsvd_pack_weights_wino(w.data_ptr(), b.data_ptr() if b is not None else None, sp.cin, sp.cout,
@@ -129,6 +151,27 @@ class PackedNet:
             # the A/B streams of streaming_forward, a graph replay): finish the one-time pack here so no consumer can see
             # half-packed weights.  (The w/b temporaries are consumed by kernels queued on this stream.)
             torch.cuda.current_stream(device).synchronize()
+
+
+    def _layer_form(self, sp, w):
+        """(F(m,3), wino_m code) of a layer that runs on the Winograd kernel, else None.  A property of the LAYER and its weights only
+        (never of the clip length, frame size or schedule): every schedule runs the same arithmetic per layer and stays bit-identical
+        to the others."""
+        if not (self.wino_m and wino_eligible(sp, self.precision, self.wino_min_cin)):
+            return None
+        m, abi = self.wino_m, self.wino_abi
+        if self.wide_conv == "wino26" and sp.cin_pad <= 128 and sp.cout_pad <= 128:
+            m = abi = 2
+        # fp16 range of the TRANSFORMED weights U = G g: |U| <= max |w| x the form's largest |G| row sum (1.5 for F(2,3), 15 for F(6,3)).
+        # A BN-folded layer inside the raw-weight guard (arch.F16X3_WEIGHT_LIMIT) can still leave fp16's range here: it keeps the direct form
+        wmax = float(w.abs().max()) if w.numel() else 0.0
+        if not wmax * WINO_G_ROW_SUM[m] <= F16_PAIR_LIMIT:
+            self.wino_range_fallback.append((sp.key, wmax, m))
+            import warnings
+            warnings.warn("bsvd_amd: %s: max |weight| %.3g x %.3g (F(%d,3) weight transform) leaves fp16's range; this layer runs "
+                          "the direct form" % (sp.key, wmax, WINO_G_ROW_SUM[m], m))
+            return None
+        return m, abi
 
 
 class HipExecutor:
@@ -309,6 +352,18 @@ class HipExecutor:
         if wp is not None:
             a.w_packed = wp.data_ptr()
         else:
+            # the Winograd kernel has no generic gather: validate what it needs HERE, before anything is issued or captured
+            # (the library would answer -19 in the middle of a forward)
+            for nm, h in (("halo_prev", halo_prev), ("halo_next", halo_next)):
+                if sp.tsm and h is not None:
+                    if h.t.data_ptr() % 16 or h.pstride % 4 or h.coff % 4:
+                        raise ValueError("%s: the Winograd form needs a 16-byte aligned %s (pointer %% 16, pstride %% 4, coff %% 4 elements); "
+                                         "got pstride %d, coff %d" % (sp.key, nm, h.pstride, h.coff))
+                    if H * W * h.pstride * 4 >= 2 ** 31 - 1:
+                        raise ValueError("%s: %s spans H*W*pstride*4 = %d bytes >= 2 GiB (32-bit byte offsets inside one frame)"
+                                         % (sp.key, nm, H * W * h.pstride * 4))
+            if x.data_ptr() % 16:
+                raise ValueError("%s: the Winograd form needs a 16-byte aligned input" % sp.key)
             a.w_wino_packed, a.wino_m = self.packed.wino[sp.key].data_ptr(), self.packed.wino_layer_abi[sp.key]
             if shared_chip and a.wino_m in (2, 6):
                 a.wino_m += 40        # never the half-height tile

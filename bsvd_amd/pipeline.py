@@ -138,14 +138,16 @@ class LiveStream:
     submission order and are byte-identical in every mode.  Not re-entrant (one stream per instance, like the reference's
     module state)."""
 
-    def __init__(self, model, sigma=None, depth=2, overlap_blocks=None):
+    def __init__(self, model, sigma=None, depth=2, overlap_blocks=None, frame_shape=None):
+        """frame_shape: optional (H, W) of the frames to come -- the overlap decision (and with it ``latency``) is then final at
+        construction instead of at the first feed."""
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.model, self.sigma, self.depth = model, sigma, depth
-        self.overlap = (depth >= 2) if overlap_blocks is None else bool(overlap_blocks)
+        self._overlap_wanted = (depth >= 2) if overlap_blocks is None else bool(overlap_blocks)
         self._overlap_explicit = overlap_blocks is not None
-        self._overlap_checked = not self.overlap
-        self.latency = model.shift_num + depth - 1 + (1 if self.overlap else 0)     # feeds between a frame going in and coming out
+        self.overlap = self._overlap_wanted
+        self._overlap_decided = not self._overlap_wanted     # nothing to decide without the lagged schedule
         self.device = model._device()
         if self.device.type != "cuda":
             raise RuntimeError("LiveStream needs the model on a HIP device (model.cuda())")
@@ -155,6 +157,38 @@ class LiveStream:
         self.inflight = collections.deque()          # (slot, has_output) in submission order
         self.count = 0
         model.reset()
+        if frame_shape is not None:
+            self._decide_overlap(int(frame_shape[0]), int(frame_shape[1]))
+
+    @property
+    def latency(self):
+        """feeds between a frame going in and coming out: ``shift_num + depth - 1``, + 1 with the lagged two-branch schedule.  Final once
+        ``latency_final`` is True -- from construction when ``frame_shape`` was given or overlap is off, else from the first feed (a default
+        ``overlap_blocks=None`` falls back to the plain per-frame feed when the ring engine is not available for the frame size)."""
+        return self.model.shift_num + self.depth - 1 + (1 if self.overlap else 0)
+
+    @property
+    def latency_final(self):
+        return self._overlap_decided
+
+    def _decide_overlap(self, h, w):
+        """The lagged two-branch schedule needs the ring engine (stream_rings, planar edge layers, rings that fit the free HBM).  Decided
+        once per stream, BEFORE its first frame touches the pipeline: a default (overlap_blocks=None) falls back to the plain per-frame
+        feed -- one feed less latency, same frames --, an explicit overlap_blocks=True raises here with the stream still untouched (and
+        the decision still open: a retried feed raises the same error again instead of failing half-way through a step).  flush() and a
+        new frame size re-open the decision."""
+        if self._overlap_decided:
+            return
+        if not self.model.overlap_available((self.model.net.net_in_ch, h, w)):
+            if self._overlap_explicit:
+                raise RuntimeError("LiveStream(overlap_blocks=True) needs the ring engine (stream_rings=True, planar edge layers, "
+                                   "enough free HBM for the rings); use overlap_blocks=False")
+            self.overlap = False
+        self._overlap_decided = True
+
+    def _reopen_overlap(self):
+        self.overlap = self._overlap_wanted
+        self._overlap_decided = not self._overlap_wanted
 
     def _alloc(self, shape):
         self.shape = shape
@@ -173,19 +207,8 @@ class LiveStream:
         return slot.pin_out.numpy().copy() if has_out else None
 
     def _step(self, frame_u8, last=False):
-        if not self._overlap_checked and frame_u8 is not None:
-            # the lagged two-branch schedule needs the ring engine (stream_rings, planar edge layers, rings that fit the free HBM).
-            # Decided ONCE, before the first frame touches the stream: a default (overlap_blocks=None) falls back to the plain
-            # per-frame feed -- one feed less latency, same frames --, an explicit overlap_blocks=True raises here, with the
-            # stream still untouched, instead of half-way through a step
-            self._overlap_checked = True
-            h, w = frame_u8.shape[:2]
-            if not self.model.overlap_available((self.model.net.net_in_ch, h, w)):
-                if self._overlap_explicit:
-                    raise RuntimeError("LiveStream(overlap_blocks=True) needs the ring engine (stream_rings=True, planar edge layers, "
-                                       "enough free HBM for the rings); use overlap_blocks=False")
-                self.overlap = False
-                self.latency -= 1
+        if frame_u8 is not None:
+            self._decide_overlap(frame_u8.shape[0], frame_u8.shape[1])
         slot = self.slots[self.count % len(self.slots)]
         self.count += 1
         with torch.cuda.device(self.device):
@@ -225,6 +248,7 @@ class LiveStream:
         if self.shape != frame_u8.shape:
             if self.inflight:
                 raise ValueError("frame size changed mid-stream; flush() first")
+            self._reopen_overlap()                    # the rings of another frame size may or may not fit
             self._alloc(frame_u8.shape)
         self._step(frame_u8)                          # step k is in flight ...
         outs = []
@@ -244,4 +268,5 @@ class LiveStream:
             self._step(None, last=True)
         self._drain(0, outs)
         self.model.reset()
+        self._reopen_overlap()                        # the next stream decides again (free HBM may have changed)
         return outs

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BSVD_ABI_VERSION 9
+#define BSVD_ABI_VERSION 10
 
 /* dtype.  BSVD_F32: exact fp32 (v_mfma_f32_32x32x2_f32).  BSVD_F16X3 ("split16"): every fp32 value v is carried as
  * an fp16 pair hi = fp16(v), lo = fp16(v - hi); a 16-channel chunk of a pixel is stored as [hi x16 | lo x16] in the
@@ -115,19 +115,25 @@ typedef struct BsvdConvArgs {
     const void *head_w_packed;
     const void *head_bias;
     /* Winograd form of a wide layer (ABI v9, BSVD_F16X3 only).  w_wino_packed != NULL selects the 1-D Winograd F(wino_m, 3)
-     * kernel (wino_m = 2, 4 or 6; conv3x3_winox.hip, one transformed position per wave; wino_m + 10 = 12 | 14 runs the
-     * all-positions-per-wave variant conv3x3_wino.hip on the same F(2,3) / F(4,3) pack, 22 / 32 force F(2,3)'s 4-wave workgroup /
-     * its half-height tile -- kept for measurements and tests; wino_m = 2 picks the half-height tile itself for grids that
-     * do not fill the chip, bit-identical to the full tile, and 42 = F(2,3) always on the full tile is for launches that run
-     * beside another stream's or graph branch's kernels; 36 / 46 are the same two for F(6,3), which picks its tile like F(2,3);
-     * 52 / 62 = F(2,3) one tile per workgroup / as persistent workgroups, whatever the grid: the persistent form is slower and
-     * never chosen by wino_m = 2) with the
-     * TRANSFORMED weights of bsvd_pack_weights_wino(); w_packed is then
-     * ignored (may be NULL).  Same contract and tensors as the direct form -- gather, halos, bias, activation, PLAIN / PS_ADD
-     * epilogues -- but 6 (F(2,3)), 4.5 (F(4,3)) or 4 (F(6,3)) instead of 9 tap-GEMMs per output pixel; results differ from the direct
-     * form in the last bits (fp32 transforms, both inside the same error class: 5e-5 max-abs on bsvd_c64), so a host must use
-     * ONE form per layer in every schedule it wants bit-identical (clip / stream / sharded).  Needs stride 1, fold % 16 == 0,
-     * Cout % 32 == 0, no planar / fused-entry / RESID options; anything else returns -19 with the reason. */
+     * kernel (conv3x3_winox.hip, one transformed position per wave) with the TRANSFORMED weights of bsvd_pack_weights_wino();
+     * w_packed is then ignored (may be NULL).  wino_m:
+     *    2 | 6    F(2,3) | F(6,3).  The kernel picks its half-height pixel tile for grids that do not fill the chip (single-frame
+     *             launches); both tiles compute every output with the same instruction sequence (bit-identical).
+     *   42 | 46   the same two forms, never on the half-height tile: for launches that run beside another stream's or graph
+     *             branch's kernels (idle CUs are not idle there).  Same bits as 2 | 6.
+     *   Other codes (F(4,3), forced tiles, 4-wave workgroups, the persistent form, the all-positions-per-wave kernel) exist in
+     *   MEASUREMENT builds of the library only (-DBSVD_MEASURE: bsvd_build_info() & BSVD_BUILD_MEASURE; tools/build_measure.sh);
+     *   the product library answers them with -19.
+     * Same contract and tensors as the direct form -- gather, halos, bias, activation, PLAIN / PS_ADD epilogues -- but 6 (F(2,3)) or
+     * 4 (F(6,3)) instead of 9 tap-GEMMs per output pixel; results differ from the direct form in the last bits (fp32 transforms,
+     * both inside the same error class: 5e-5 max-abs on bsvd_c64), so a host must use ONE form per layer in every schedule it wants
+     * bit-identical (clip / stream / sharded).  Needs stride 1, fold % 16 == 0, Cout % 32 == 0, 16-byte aligned x / halo pointers
+     * and strides, H*W*Cin*4 and H*W*halo_pstride*4 < 2 GiB, no planar / fused-entry / RESID options; anything else returns -19
+     * with the reason -- never a silent direct launch.
+     * fp16 range: the kernel converts TRANSFORMED activations (sums of up to 2x / 4.7x the inputs for F(2,3) / F(6,3)) with
+     * saturating conversions (MODE.FP16_OVFL): unchanged below 65504, a pair still carries a transformed value up to 131008 (at
+     * reduced precision, relative 2^-13) and saturates beyond; finite inputs never produce inf / NaN.  Weights: bsvd_pack_weights_wino saturates U = G g at +-65504; a host should keep a
+     * layer whose max |w| x (largest |G| row sum: 1.5 / 15.04) leaves fp16's range on the direct form (bsvd_amd.engine does). */
     const void *w_wino_packed;
     int32_t wino_m;
     /* Tuning (ABI v9; 0 = the library's measured default, 800): the smallest grid, in 256-px x 128-channel workgroups, for which a
@@ -138,6 +144,10 @@ typedef struct BsvdConvArgs {
 
 int bsvd_abi_version(void);
 int bsvd_conv_args_size(void);   /* sizeof(BsvdConvArgs) as compiled into the library (binding sanity check) */
+/* ABI v10: bit set of how this library was built.  BSVD_BUILD_MEASURE: a measurement build (-DBSVD_MEASURE) that also contains
+ * the kernel variants DESIGN.md 4.1d records as slower (more wino_m codes); the product library returns 0. */
+#define BSVD_BUILD_MEASURE 1
+int bsvd_build_info(void);
 const char *bsvd_last_error(void);
 
 /* The fused layer above (BSVD_F32: exact fp32 MFMA; BSVD_F16X3: split-fp16 3-pass MFMA). */

@@ -11,6 +11,8 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "measure: runs on a MEASUREMENT build of the library (tools/build_measure.sh, build/measure/), "
+                                       "in a subprocess; never the product libbsvd_hip.so")
 
 
 @pytest.fixture(scope="session")

@@ -31,7 +31,9 @@ def draw(rs):
 def nets(n):
     """whole bsvd_c64 / c32-sized networks on small random clips with every wide layer on the fat tile: clip vs the oracle in both
     precisions, stream schedule bit-identical (tests/test_gpu_fuzz.py::test_random_clip_whole_network under the override)"""
+    import bsvd_amd.arch as A
     import test_gpu_fuzz as F
+    A.WIDE_CONV_DEFAULT = "direct"      # the direct form of the wide layers (the fat tile) for every model this process builds
     for seed in range(n):
         print("net case", seed, flush=True)
         F.test_random_clip_whole_network(seed)

@@ -60,6 +60,60 @@ def test_sharded_clip_over_gloo(world, tmp_path):
     assert maxabs(y, g["out"][0]) < 1e-4
 
 
+def _worker80(rank, world, port, outdir):
+    for p in (os.path.dirname(HERE), HERE, os.path.join(HERE, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle_exec import OracleExecutor
+    from bsvd_amd.dist import HaloExchanger, shard_range
+    from bsvd_amd.netspec import make_netspec
+    from bsvd_amd.schedule import bsvd_clip
+    g = load_golden("g4_bsvd_small_T7")
+    st = state_for(g, bsvd_keys([32, 64, 128], 32, 4, 3, 32))
+    net = make_netspec([32, 64, 128], 32, 4, 3, "relu6", 32)
+    x = torch.from_numpy(np.load(os.path.join(outdir, "x80.npy")))
+    a, b = shard_range(x.shape[0], world, rank)
+    assert b - a == 10                                   # BASELINE config 4: 80 frames, 10 per rank
+    ex = OracleExecutor(st)
+    hx = HaloExchanger(ex, rank, world)
+    y = ex.to_nchw(bsvd_clip(ex, net, ex.to_nhwc(x[a:b], 16), hx), 3)
+    assert hx.exchanges == 16                            # one per temporal-fusion layer, interior ranks on both sides
+    np.save(os.path.join(outdir, "out%d.npy" % rank), y.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c4_80_frames_over_8_real_gloo_ranks(tmp_path):
+    """BASELINE config 4's split -- one 80-frame clip, 8 ranks x 10 frames, a 1-frame halo per temporal-fusion layer and boundary -- as
+    EIGHT REAL PROCESSES over gloo (world 2 / 3 above, the stub fabric below at 3 / 8): the concatenated shard outputs
+    equal the unsharded clip of the same executor to fp32 rounding (16 x 2 messages per interior rank; ranks 0 and 7 have one neighbour).
+    (The CPU executor's torch.conv2d picks batch- and thread-dependent kernels, so 10-frame and 80-frame calls differ in the last bit;
+    BIT equality of the sharded schedule is the GPU suite's test_gpu_fullsize.py::test_80_frames_in_8_shards on the HIP kernels.)"""
+    from oracle_exec import OracleExecutor
+    from bsvd_amd.netspec import make_netspec
+    from bsvd_amd.schedule import bsvd_clip
+    g = load_golden("g4_bsvd_small_T7")
+    st = state_for(g, bsvd_keys([32, 64, 128], 32, 4, 3, 32))
+    net = make_netspec([32, 64, 128], 32, 4, 3, "relu6", 32)
+    rs = np.random.RandomState(80)
+    x = rs.rand(80, 4, 8, 12).astype(np.float32)
+    np.save(tmp_path / "x80.npy", x)
+    port = _free_port()
+    mp.spawn(_worker80, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    y = np.concatenate([np.load(tmp_path / ("out%d.npy" % r)) for r in range(8)])
+    ex = OracleExecutor(st)
+    want = ex.to_nchw(bsvd_clip(ex, net, ex.to_nhwc(torch.from_numpy(x), 16), None), 3).numpy()
+    assert y.shape == want.shape == (80, 3, 8, 12)
+    assert maxabs(y, want) < 2e-5, maxabs(y, want)
+    # a wrong or missing halo is not a rounding matter: without any exchange the shard boundaries are off by orders of magnitude more
+    lone = np.concatenate([ex.to_nchw(bsvd_clip(ex, net, ex.to_nhwc(torch.from_numpy(x[a:a + 10]), 16), None), 3).numpy() for a in range(0, 80, 10)])
+    assert maxabs(lone, want) > 1e-2
+
+
 def test_shard_range_covers_clip():
     from bsvd_amd.dist import shard_range
     for n in (1, 7, 10, 80, 85):

@@ -261,12 +261,21 @@ def test_live_stream_falls_back_when_the_ring_engine_is_unavailable():
     frames = rs.randint(0, 256, (19, 32, 48, 3)).astype(np.uint8)
     want = output_to_frames(m.clip_forward(frames_to_input(torch.from_numpy(frames).to(dev), sigma))).cpu().numpy()
     live = LiveStream(m, sigma=sigma, depth=2)
-    assert live.overlap and live.latency == m.shift_num + 2
+    assert live.overlap and live.latency == m.shift_num + 2 and not live.latency_final
     got = [r for r in (live.feed(f) for f in frames) if r is not None]
-    assert not live.overlap and live.latency == m.shift_num + 1          # decided at the first frame
+    assert not live.overlap and live.latency == m.shift_num + 1 and live.latency_final     # decided at the first frame
     got += live.flush()
     assert len(got) == 19 and np.array_equal(np.stack(got), want)
+    # flush() re-opens the decision for the next stream (the free HBM or the frame size may have changed) ...
+    assert live.overlap and not live.latency_final
+    got2 = [r for r in (live.feed(f) for f in frames) if r is not None] + live.flush()
+    assert np.array_equal(np.stack(got2), want)
+    # ... a frame shape at construction makes the latency final before the first feed ...
+    early = LiveStream(m, sigma=sigma, depth=2, frame_shape=frames.shape[1:3])
+    assert early.latency_final and not early.overlap and early.latency == m.shift_num + 1
+    # ... and an explicit request raises with the stream untouched, AGAIN on a retried feed (the decision stays open)
     strict = LiveStream(m, sigma=sigma, depth=2, overlap_blocks=True)
-    with pytest.raises(RuntimeError, match="ring engine"):
-        strict.feed(frames[0])
-    assert strict.count == 0 and not strict.inflight                     # nothing half-advanced
+    for _ in range(2):
+        with pytest.raises(RuntimeError, match="ring engine"):
+            strict.feed(frames[0])
+        assert strict.count == 0 and not strict.inflight and not strict.latency_final      # nothing half-advanced

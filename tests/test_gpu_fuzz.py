@@ -48,11 +48,11 @@ def test_random_layer_split_fp16(seed):
 @pytest.mark.parametrize("seed", range(36))
 def test_random_wide_layer_winograd_forms(seed):
     """The Winograd kernels on random eligible layers (stride 1, 128 / 256 input channels; bsvd_arch.py:21-50, :257-267): ragged sizes in
-    both directions, 1 to 3 frames, every halo form of the temporal gather, PixelShuffle + skip, the three activations; every kernel variant
-    in turn (F(2,3) / F(4,3) / F(6,3), their 8-row tiles, the 4-wave and the persistent F(2,3))."""
+    both directions, 1 to 3 frames, every halo form of the temporal gather, PixelShuffle + skip, the three activations; F(2,3) and F(6,3)
+    in turn (the measurement variants draw from the same generator in tests/measure_driver.py)."""
     import test_gpu_wino as WN
     rs = np.random.RandomState(7000 + seed)
-    form = ["wino2", "wino6", "wino2h", "wino4", "wino6h", "wino2p", "wino2s"][seed % 7]
+    form = WN.PRODUCT_FORMS[seed % 2]
     epi = int(rs.choice([0, 0, 1]))
     tsm = bool(epi == 0 and rs.rand() < 0.6)
     cin = int(rs.choice([128, 256]))
@@ -143,7 +143,7 @@ def test_random_networks_with_the_wide_layers_forced_onto_the_128_accumulator_ti
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, BSVD_FAT_MIN_WGS="1", BSVD_WIDE_CONV="direct", PYTHONDONTWRITEBYTECODE="1")      # the direct form of the wide layers
+    env = dict(os.environ, BSVD_FAT_MIN_WGS="1", PYTHONDONTWRITEBYTECODE="1")      # ("nets": the driver builds its models with wide_conv='direct')
     r = subprocess.run([sys.executable, os.path.join(here, "fat_tile_fuzz_driver.py"), "6", "nets"], env=env, capture_output=True,
                        text=True, timeout=900)
     print(r.stdout[-3000:])

@@ -36,7 +36,12 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("wide_conv", ["wino2", "wino4", "wino6", "wino2b", "wino2s", "wino2h", "wino2p", "wino6h"])
+# the forms of the product library; the measurement variants (F(4,3), forced tiles, 4-wave workgroups, the persistent form, the
+# all-positions-per-wave kernel) run the same cases from tests/measure_driver.py on a -DBSVD_MEASURE build (test_gpu_measure.py)
+PRODUCT_FORMS = ["wino2", "wino6"]
+
+
+@pytest.mark.parametrize("wide_conv", PRODUCT_FORMS)
 @pytest.mark.parametrize("cin,cout,tsm,act,epi,T,H,W", CASES)
 def test_wino_layer_vs_oracle(wide_conv, cin, cout, tsm, act, epi, T, H, W):
     from bsvd_amd.netspec import ConvSpec
@@ -75,35 +80,70 @@ def test_wino_layer_vs_oracle(wide_conv, cin, cout, tsm, act, epi, T, H, W):
         assert err < TIGHT
 
 
+def _conv_with_code(gex, sp, x, code, hp=None, hn=None):
+    """one launch with an explicit BsvdConvArgs.wino_m (2 = the kernel picks its tile, 42 = never the half-height tile)"""
+    import ctypes
+    from bsvd_amd import _lib
+    a, y = gex.build_args(sp, x, hp, hn)
+    a.wino_m = code
+    buf = ctypes.create_string_buffer(96)
+    _lib.check(gex.lib.bsvd_conv3x3_variant(ctypes.byref(a), buf, 96), "variant")
+    _lib.check(gex.lib.bsvd_conv3x3(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "conv")
+    return y, buf.value.decode()
+
+
 def test_half_height_tile_is_bit_identical_and_taken_by_grids_that_do_not_fill_the_chip():
     """wino_m = 2 launches the 8-row tile when the 16-row grid would leave CUs idle (single-frame launches of the stream schedules:
     256 -> 256 at 135 x 240 is 270 workgroups on 256 CUs); both tiles run the same instruction sequence per output, so the choice --
-    which depends on the launch's size -- cannot break stream == clip (bsvd_arch.py:485-552 vs :555-569)."""
+    which depends on the launch's size -- cannot break stream == clip (bsvd_arch.py:485-552 vs :555-569).  wino_m = 42 (launches that
+    share the chip with another graph branch) never takes it: same bits."""
     from bsvd_amd.netspec import ConvSpec
+    from bsvd_amd.schedule import Halo
     rs = np.random.RandomState(5)
-    outs = {}
     for cin, H, W, want_half in ((128, 270, 480, False), (256, 135, 240, True)):
         sp = ConvSpec("l", "l", cin, cin, 1, True, "relu6", 0)
         st = seeded_state([("e0.weight", (16, 4, 3, 3)), ("e0.bias", (16,)), ("l.weight", (cin, cin, 3, 3)),
                            ("l.bias", (cin,)), ("e1.weight", (3, 16, 3, 3)), ("e1.bias", (3,))], 7)
         x = to_split(torch.from_numpy(rs.standard_normal((1, H, W, cin)).astype(np.float32))).to(_dev())
-        for form in ("wino2", "wino2h"):
-            gex = _exec(_Net(sp), st, form)
-            gex.record_variants = True
-            outs[form] = gex.conv(sp, x).clone()
-            half = gex.last_variant.endswith("[8 rows]")
-            assert half == (want_half or form == "wino2h"), (form, cin, gex.last_variant)
-        assert torch.equal(outs["wino2"], outs["wino2h"])
+        gex = _exec(_Net(sp), st, "wino2")
+        y_auto, v_auto = _conv_with_code(gex, sp, x, 2)
+        y_full, v_full = _conv_with_code(gex, sp, x, 42)
+        assert v_auto.endswith("[8 rows]") == want_half and not v_full.endswith("[8 rows]"), (cin, v_auto, v_full)
+        assert torch.equal(y_auto, y_full)
         if want_half:       # ... and a 10-frame clip of the same layer takes the full tile and produces the same bits per frame
-            gex = _exec(_Net(sp), st, "wino2")
             gex.record_variants = True
-            from bsvd_amd.schedule import Halo
             x10 = x.expand(10, -1, -1, -1).contiguous()
             y10 = gex.conv(sp, x10)
             assert not gex.last_variant.endswith("[8 rows]"), gex.last_variant
             y1 = gex.conv(sp, x, Halo(x, cin, sp.fold), Halo(x, cin, 0))     # frame 5's neighbours = the same frame
             assert gex.last_variant.endswith("[8 rows]")
             assert torch.equal(y10[5:6], y1)
+
+
+def test_product_library_has_no_measurement_variants():
+    """the kernel variants DESIGN 4.1d records as slower live in measurement builds only.  The in-tree library
+    reports a product build, the engine refuses their names, and the ABI answers their wino_m codes with -19."""
+    import ctypes
+    import os
+    from bsvd_amd import _lib, engine
+    from bsvd_amd.netspec import ConvSpec
+    lib = _lib.load()
+    if os.environ.get("BSVD_HIP_LIB"):
+        pytest.skip("a library override is active")
+    assert lib.bsvd_build_info() & _lib.BUILD_MEASURE == 0
+    assert engine.WIDE_CONV == ("direct", "wino2", "wino6", "wino26")
+    sp = ConvSpec("l", "l", 128, 128, 1, True, "relu6", 0)
+    st = seeded_state([("e0.weight", (16, 4, 3, 3)), ("e0.bias", (16,)), ("l.weight", (128, 128, 3, 3)),
+                       ("l.bias", (128,)), ("e1.weight", (3, 16, 3, 3)), ("e1.bias", (3,))], 7)
+    for name in engine.MEASURE_WIDE_CONV:
+        with pytest.raises(ValueError, match="measurement"):
+            _exec(_Net(sp), st, name)
+    gex = _exec(_Net(sp), st, "wino2")
+    x = to_split(torch.zeros(1, 8, 16, 128)).to(_dev())
+    a, _ = gex.build_args(sp, x)
+    for code in (4, 12, 14, 22, 32, 36, 52, 62):
+        a.wino_m = code
+        assert lib.bsvd_conv3x3(ctypes.byref(a), None) == -19 and b"measurement" in lib.bsvd_last_error(), code
 
 
 @pytest.mark.parametrize("wide_conv", ["wino2", "wino6"])

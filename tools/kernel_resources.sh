@@ -3,7 +3,9 @@
 # usage: [EXTRA_HIPCC_FLAGS=...] tools/kernel_resources.sh   -> builds into a scratch object dir, prints one line per kernel
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=$(mktemp -d)
-for src in conv3x3_mfma conv3x3_wino conv3x3_winox conv3x3_edge_f32 bsvd_abi; do
+SRCS="conv3x3_mfma conv3x3_winox conv3x3_edge_f32 bsvd_abi"
+case " ${EXTRA_HIPCC_FLAGS} " in *" -DBSVD_MEASURE"*) SRCS="$SRCS conv3x3_wino";; esac      # measurement builds only (bsvd_amd/csrc/build.sh)
+for src in $SRCS; do
   XF=""; [ "$src" = conv3x3_winox ] && XF="-fno-slp-vectorize"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$ROOT/bsvd_amd/csrc -Wno-unused-function \
      $XF ${EXTRA_HIPCC_FLAGS} -Rpass-analysis=kernel-resource-usage -c $ROOT/bsvd_amd/csrc/$src.hip -o $OUT/$src.o 2> $OUT/$src.log &

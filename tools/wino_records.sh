@@ -30,7 +30,7 @@ cp $O/pmc_${TAG}wino/summary.txt $O/${TAG}_wino_pmc_summary.txt
 # 6. the whole C1 clip per form, interleaved
 { for round in 1 2; do for form in direct wino2 wino4 wino6; do
     echo -n "[$round] $form: "
-    BSVD_WIDE_CONV=$form python bench.py --no-cpu-baseline --no-power-probe --steps 20 --warmup 3 2>/dev/null | python -c "
+    python bench.py --wide-conv $form --no-cpu-baseline --no-power-probe --steps 20 --warmup 3 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
 print('%.1f frames/s  parity vs exact fp32 %.2e  dominant %s %.3f ms avg, %.0f TFLOP/s algorithmic, %.0f issued' % (d['value'], d['parity']['max_abs_f16x3_vs_exact_fp32_on_this_clip'], r['kernel'], r['avg_launch_ms'], r['achieved'], r['mfma_pipe_frac'] * r['peak']))"
