@@ -66,15 +66,17 @@ def synth_clip(frames, seed, device, h=None, w=None):
     return lq.to(device), nm.to(device)
 
 
-def build_model(device, precision="fp32", blind=False, wide_conv="auto"):
+def build_model(device, precision="fp32", blind=False, wide_conv="auto", fuse_pairs="auto"):
     import bsvd_amd
     torch.manual_seed(1234)      # random-init weights of the bsvd_c64 architecture (no checkpoint in the tree)
     if blind:                    # options/test/0407...blind_c64.yml:97-121: interm_ch default 30, act default relu
         m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, shift_input=False, in_ch=4, out_ch=3, norm="none",
-                          act="relu", interm_ch=30, blind=True, pretrain_ckpt=None, precision=precision, wide_conv=wide_conv)
+                          act="relu", interm_ch=30, blind=True, pretrain_ckpt=None, precision=precision, wide_conv=wide_conv,
+                          fuse_pairs=fuse_pairs)
     else:
         m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, shift_input=False, in_ch=4, out_ch=3, norm="none",
-                          act="relu6", interm_ch=64, blind=False, pretrain_ckpt=None, precision=precision, wide_conv=wide_conv)
+                          act="relu6", interm_ch=64, blind=False, pretrain_ckpt=None, precision=precision, wide_conv=wide_conv,
+                          fuse_pairs=fuse_pairs)
     return m.to(device).eval()
 
 
@@ -110,6 +112,8 @@ def mfma_factor(kernel_name):
     """MFMA flop issued per algorithmic flop by a kernel variant (name as bsvd_conv3x3_variant reports it)"""
     import re
     passes = 3.0 if "f16x3" in kernel_name else 1.0
+    if "[fused pair]" in kernel_name:       # the first conv runs on 12 MFMA row tiles (384 pixel slots) per 256 output pixels: 1.5x its share (half of an equal pair)
+        passes *= 1.25
     m = re.search(r"F\((\d),3\)", kernel_name)                   # Winograd F(m,3) along x: 3 (m + 2) tap-GEMMs per m outputs instead of 9 per output
     return passes * ((m_ := int(m.group(1))) + 2) * 3.0 / (9.0 * m_) if m else passes
 
@@ -128,6 +132,8 @@ class LaunchTimer:
         ex.conv = self._conv
         self._orig_fused = ex.conv_head_fused
         ex.conv_head_fused = self._fused
+        self._orig_pair = ex.conv_pair_fused
+        ex.conv_pair_fused = self._pair
 
     def _event(self):
         if self.used == len(self.pool):
@@ -176,6 +182,26 @@ class LaunchTimer:
         self.records.append((both, T, Hh, Ww, e0, e1, name, 0, algorithmic_bytes(both, T, Hh, Ww, x.shape[1])))
         return y
 
+    def _pair(self, spa, spb, x, *a, **k):
+        """a fused pair of plain convs as one launch: its algorithmic FLOP and bytes are the two convs' without the tensor between them"""
+        key = (spb.key, tuple(x.shape), "pair", bool(k.get("y_planar")))
+        name = self.names.get(key)
+        self.ex.record_variants = name is None
+        e0, e1 = self._event(), self._event()
+        e0.record()
+        y = self._orig_pair(spa, spb, x, *a, **k)
+        e1.record()
+        if name is None:
+            name = self.names[key] = self.ex.last_variant
+        T, Hh, Ww, _ = x.shape
+        both = _Both(spa, spb)
+        yp = k.get("y_planar")
+        extra = k.get("extra") if "extra" in k else (a[0] if len(a) > 0 else None)
+        nb = T * Hh * Ww * 4 * (spa.cin_pad + (yp[0] if yp else spb.cout_pad) + (min(3, spb.cout) if extra is not None else 0)) + \
+            (spa.cin_pad * 9 * spa.cout_pad + spb.cin_pad * 9 * spb.cout_pad) * 4
+        self.records.append((both, T, Hh, Ww, e0, e1, name, 0, nb))
+        return y
+
     def reserve(self, steps):
         """grow the pool to `steps` x (events used since the last reset), creating the HIP events now (record() creates)"""
         need = steps * max(self.used, 1)
@@ -191,6 +217,7 @@ class LaunchTimer:
     def detach(self):
         self.ex.conv = self._orig
         self.ex.conv_head_fused = self._orig_fused
+        self.ex.conv_pair_fused = self._orig_pair
         self.ex.record_variants = False
 
     def summary(self):
@@ -360,6 +387,8 @@ def main():
                     help="weak: --frames per GPU (the job grows with N); strong: one clip of --total-frames split over the ranks")
     ap.add_argument("--total-frames", type=int, default=80, help="--scaling strong: frames of the whole clip (C4: 80)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fuse-pairs", default="auto", choices=["auto", "on", "off"],
+                    help="the 64-channel full-resolution conv pairs as one launch each (BSVD(fuse_pairs=...); auto = the product default)")
     ap.add_argument("--wide-conv", default="auto", help="arithmetic form of the wide split-fp16 layers: auto (= wino2) | direct | wino2 | wino6 | "
                                                         "wino26 (bsvd_amd.engine.WIDE_CONV; the driver's line runs the default)")
     ap.add_argument("--no-power-probe", action="store_true", help="skip the 2.5 s rocm-smi power / clock sample after the timed region")
@@ -438,7 +467,7 @@ def main():
     def timed_run(precision, steps, warmup, prewarm_s=0.0, instrument=True, probe_s=0.0):
         """W untimed + K timed steps of the hot path at `precision`; returns (model, max-over-ranks seconds, per-kernel
         launch timings, last output)."""
-        model = build_model(device, precision, wl["blind"], args.wide_conv)
+        model = build_model(device, precision, wl["blind"], args.wide_conv, {"auto": "auto", "on": True, "off": False}[args.fuse_pairs])
         ex = model._executor(device)
         halo_fn = None
         if world > 1:
@@ -592,7 +621,7 @@ def main():
                                    % (api, "; frame-window sharded with per-layer RCCL halo" if world > 1 else ""),
                        "baseline_config": args.workload if world == 1 or args.workload != "c1" else "c4" if frames * world == 80 else "c1 x%d" % world,
                        "frames_per_gpu": frames, "parallelism": "frame-window x%d" % world,
-                       "schedule": mode, "halo_transport": halo_transport, "wide_conv": model.wide_conv,
+                       "schedule": mode, "halo_transport": halo_transport, "wide_conv": model.wide_conv, "fuse_pairs": model.fuse_pairs,
                        "flop_per_frame": flop_per_frame},
             # true when the halo slices of an N>1 run did NOT travel over RCCL/xGMI (host-staged gloo fallback): such a line is a
             # functional check, not a scaling measurement

@@ -54,6 +54,9 @@ class BsvdConvArgs(ctypes.Structure):
         ("w_wino_packed", ctypes.c_void_p),
         ("wino_m", ctypes.c_int32),
         ("fat_min_wgs", ctypes.c_int32),
+        ("pre_w_packed", ctypes.c_void_p),
+        ("pre_bias", ctypes.c_void_p),
+        ("pre_cin", ctypes.c_int32), ("pre_act", ctypes.c_int32),
     ]
 
 

@@ -361,6 +361,7 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
     p.extra_split = a->extra_split;
     p.y_planar_ch = a->y_planar_ch; p.y_clamp = a->y_clamp; p.y_lo = a->y_lo; p.y_hi = a->y_hi;
     p.head_w = nullptr; p.head_bias = nullptr; p.head_cin = 0;
+    p.pre_w = nullptr; p.pre_bias = nullptr; p.pre_cin = 0; p.pre_act = 0;
 #ifdef BSVD_ABLATE
     if (const char *e = getenv("BSVD_ABLATE")) p.ablate = atoi(e);
 #endif
@@ -372,6 +373,26 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
         if (p.wino_m >= 10 && p.wino_m < 20) return launch_wino(p, (hipStream_t)stream, name, name_len);
 #endif
         return launch_winox(p, (hipStream_t)stream, name, name_len);
+    }
+    if (a->pre_w_packed) {       // fused pair of plain stride-1 convs: explicit request, never a silent two-launch fall-back
+        if (a->dtype != BSVD_F16X3) { set_error("bsvd_conv3x3: the fused pair (pre_w_packed) is a BSVD_F16X3 kernel"); return -20; }
+        if (a->x_planar_ch > 0 || a->head_w_packed) { set_error("bsvd_conv3x3: pre_w_packed: not with a planar input / fused entry"); return -20; }
+        if (a->stride != 1 || a->fold != 0 || a->epilogue == BSVD_EPI_PS_ADD) { set_error("bsvd_conv3x3: fused pair needs stride 1, fold 0, PLAIN / RESID"); return -20; }
+        if (a->pre_cin <= 0 || (a->pre_cin & 15) || (a->Cin & 31) || a->Cout > 64) {
+            set_error("bsvd_conv3x3: fused pair needs pre_cin %% 16 == 0, Cin %% 32 == 0, Cout <= 64 (pre_cin %d, Cin %d, Cout %d)", a->pre_cin, a->Cin, a->Cout); return -20;
+        }
+        if (a->pre_act < BSVD_ACT_NONE || a->pre_act > BSVD_ACT_RELU6) { set_error("bsvd_conv3x3: pre_act %d", a->pre_act); return -20; }
+        if (!a->pre_bias || (((uintptr_t)a->pre_w_packed) & 15) || (((uintptr_t)a->pre_bias) & 15) || (((uintptr_t)a->x) & 15) || (a->x_frame_stride & 3)) {
+            set_error("bsvd_conv3x3: fused pair needs 16-byte aligned x, pre_w_packed and pre_bias"); return -20;
+        }
+        if ((int64_t)a->H * a->W * (a->pre_cin > a->Cout ? a->pre_cin : a->Cout) * 4 >= 0x7fffffffLL ||
+            (int64_t)a->pre_cin * 9 * a->Cin * 4 >= 0x7fffffffLL) { set_error("bsvd_conv3x3: frame / weights too large for the fused pair (2 GiB byte offsets)"); return -20; }
+        p.pre_w = a->pre_w_packed; p.pre_bias = (const float *)a->pre_bias; p.pre_cin = a->pre_cin; p.pre_act = a->pre_act;
+        p.vec_ok = 1;
+        if (a->y_planar_ch > 0) {
+            if (a->Cout != 16 || a->y_planar_ch > 4 || (a->epilogue == BSVD_EPI_RESID && a->resid_ch > a->y_planar_ch)) { set_error("bsvd_conv3x3: fused pair with a planar output needs Cout == 16 and 1..4 planar channels"); return -20; }
+        }
+        return launch_conv3x3(p, 1, (hipStream_t)stream, name, name_len);
     }
     if (a->x_planar_ch > 0 || a->y_planar_ch > 0) {
         if (a->x_planar_ch > 0 && a->y_planar_ch > 0) { set_error("bsvd_conv3x3: x_planar_ch and y_planar_ch are exclusive"); return -16; }

@@ -34,6 +34,11 @@ struct ConvParams {
     const void *head_w;
     const float *head_bias;
     int32_t head_cin;
+    // fused 64-channel pair (BsvdConvArgs.pre_w_packed): x is the FIRST conv's NHWC input with pre_cin channels, pre_w its split pack
+    // (pre_cin -> Cin channels), pre_bias [Cin] fp32, pre_act its activation; w / bias / act / epilogue describe the second conv
+    const void *pre_w;
+    const float *pre_bias;
+    int32_t pre_cin, pre_act;
     // Winograd form of the wide split-fp16 layers (BsvdConvArgs.w_wino_packed): w then points at the transformed pack
     int32_t fat_min_wgs;     // BsvdConvArgs.fat_min_wgs (0 = default): smallest grid that takes the 128-accumulator split tile
     int32_t wino_m;          // 0 = direct convolution; 2 | 4 | 6 = F(wino_m, 3) along x (conv3x3_winox.hip); 12 | 14 = the all-positions-per-wave kernel (conv3x3_wino.hip)

@@ -350,9 +350,14 @@ __device__ __forceinline__ void tl_stamp(int slot, int k)
 // first conv's output (head_cin -> Cin channels, act, zero outside the image) on its own 18 x 18 patch with MFMAs
 // (K = 9 taps x 4 channels, padded to 48) straight into the LDS patch buffers, a pair of 16-channel chunks at a time, and
 // never reads an NHWC input tensor.  See head_pair below.
-template <class C, bool FAST, int PREC, bool MIXF = false, bool HEADF = false>
-__global__ __launch_bounds__(256, (occ_of<C, PREC, MIXF>())) void conv3x3_kernel(const ConvParams p)
+// PREF (fused 64-channel pair, BsvdConvArgs.pre_w_packed): p.x is the input of a FIRST 3 x 3 conv (pre_cin -> Cin channels, act, zero
+// outside the image); the tile computes that conv's output on its own 18 x 18 patch -- full K = 9 pre_cin, the input patch staged
+// chunk by chunk through a third LDS buffer -- a pair of 16-channel chunks at a time, straight into the two patch buffers of the main
+// conv, and the Cin-channel tensor between the two convs never exists in HBM.  See pre_pair below and DESIGN.md 4.1e.
+template <class C, bool FAST, int PREC, bool MIXF = false, bool HEADF = false, bool PREF = false>
+__global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void conv3x3_kernel(const ConvParams p)
 {
+    constexpr bool FRONT = HEADF || PREF;      // the main conv's input chunks are produced inside the tile, not loaded
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *const patch_buf = smem;                              // 2 x PATCH_FLOATS
 
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC, MIXF>())) void conv3x3_kernel
     // is all zeros, so its chunks are left out of the K loop: chunk_src / load_b below take LIVE chunk / step indices and map
     // them (i -> i + zs_a, then + zs_c from zs_b on).  Adding exact zero products leaves an fp32 accumulator bit for bit as it
     // was, so the output is identical; a 10-frame clip saves 2/10 x 1/8 of the MFMAs of its 16 temporal-fusion layers.
-    constexpr bool ZSKIP = BSVD_TUNE_ZSKIP && FAST && PREC == 1 && !MIXF && !HEADF && C::DBUF && C::RING == 3 && C::STRIDE == 1 &&
+    constexpr bool ZSKIP = BSVD_TUNE_ZSKIP && FAST && PREC == 1 && !MIXF && !FRONT && C::DBUF && C::RING == 3 && C::STRIDE == 1 &&
                            (BSVD_TUNE_APFL & 1) && C::MT * C::NT >= 8;
     int ncb = p.Cin >> 4;
     [[maybe_unused]] int zs_a = 0, zs_b = 0, zs_c = 0;
@@ -562,8 +567,10 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC, MIXF>())) void conv3x3_kernel
 
         // ---- prologue: weights of steps 0 and 1 in flight, chunk 0 patch -> LDS
         f32x4 b0[C::NT][2], b1[C::NT][2], b2[C::NT][2];
-        load_b(0, b0);
-        if constexpr (C::RING == 3) load_b(1, b1);
+        if constexpr (!PREF) {          // (fused pair: the main conv's first slabs are requested at the end of every pre_pair instead)
+            load_b(0, b0);
+            if constexpr (C::RING == 3) load_b(1, b1);
+        }
         if constexpr ((BSVD_ABL & 4) != 0) load_b(2, b2);     // (timing only: the ring keeps these three slabs for the whole tile)
         // whole patch in flight at once, then published: one HBM latency per tile instead of one per slice
         auto fill_patch = [&](const ChunkSrc &c, float *pb) {
@@ -747,7 +754,161 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC, MIXF>())) void conv3x3_kernel
                 }
             }
         };
-        if constexpr (HEADF) {
+        // ---- fused first conv of a 64-channel pair (PREF).  Stage buffer behind the two patch buffers: the first conv's input patch
+        //      (TH + 4) x (TW + 4) pixels of ONE 16-channel chunk, quad-planar like the patch buffers (row pitch a multiple of 256 B:
+        //      conflict-free fragment reads).  Chunk ci + 1 waits in registers (`phold`) while chunk ci is consumed, like the stride-2
+        //      tile's register double buffer; every input chunk is fetched once per channel pair (twice per tile for 64 channels: the
+        //      second pass comes from L2).
+        //      Arithmetic per output of the first conv = the stand-alone kernel's: the same three MFMAs per (chunk, tap) in the same
+        //      order on an fp32 accumulator, bias, activation, split -- fused == unfused bit for bit (tests/test_gpu_pair.py).
+        constexpr int SPH = C::TH + 4, SPW = C::TW + 4;
+        constexpr int S_ROWP = ((SPW * 64 + 255) / 256 * 256) / 4, S_PLANE = SPW * 4;       // floats
+        constexpr int SNITEM = SPH * SPW * 4, SNI = (SNITEM + 255) / 256;
+        [[maybe_unused]] float *const stg = smem + C::LDS_BYTES / 4;
+        [[maybe_unused]] f32x4 phold[PREF ? SNI : 1];
+        [[maybe_unused]] const int pre_nci = p.pre_cin >> 4;
+        [[maybe_unused]] auto pre_item = [&](int i, unsigned &voff, int &loff, bool &in_patch) {
+            const int e = tid + 256 * i;
+            const int prow = e / (SPW * 4), rem2 = e - prow * (SPW * 4);
+            const int pc = rem2 >> 2, q4 = rem2 & 3;
+            const int gy = iy0 - 1 + prow, gxx = ix0 - 1 + pc;
+            in_patch = e < SNITEM;
+            const bool ok = in_patch && gy >= 0 && gy < p.H && gxx >= 0 && gxx < p.W;
+            voff = ok ? (unsigned)(gy * p.W + gxx) * ((unsigned)p.pre_cin * 4u) + q4 * 16u : BSVD_OOB;
+            loff = prow * S_ROWP + q4 * S_PLANE + pc * 4;
+        };
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_pre = make_rsrc(s.cur, PREF ? hw * (unsigned)p.pre_cin * 4u : 0u);
+        [[maybe_unused]] auto pre_request = [&](int ci, bool live) {       // chunk ci of the input patch -> phold (zero-size descriptor: nothing)
+            const __amdgpu_buffer_rsrc_t r = live ? rs_pre : make_rsrc(s.cur, 0u);
+#pragma unroll
+            for (int i = 0; i < SNI; ++i) {
+                unsigned voff; int lo; bool inp;
+                pre_item(i, voff, lo, inp);
+                if constexpr (PREF) phold[i] = buf_load4_act(r, voff, (unsigned)ci * 64u);
+            }
+        };
+        [[maybe_unused]] auto pre_publish = [&]() {
+#pragma unroll
+            for (int i = 0; i < SNI; ++i) {
+                unsigned voff; int lo; bool inp;
+                pre_item(i, voff, lo, inp);
+                if constexpr (PREF) if (inp) *reinterpret_cast<f32x4 *>(stg + lo) = phold[i];
+            }
+        };
+        [[maybe_unused]] auto pre_pair = [&](int pair, int bstep) {
+            static_assert(!PREF || (C::QPL && C::STRIDE == 1 && C::DBUF && PREC == 1 && C::NT == 1), "fused pair: quad-planar stride-1 split tile, 32-channel wave tiles");
+            constexpr int NPIX = C::PH * C::PW, NRT = (NPIX + 31) / 32, NJ = (NRT + 3) / 4;     // 324 pixels, 11 row tiles, <= 3 per wave
+            const int npairs = p.Cin >> 5;
+            // this wave's row tiles wid, wid + 4, ...: lane pixel -> offset in the stage buffer / the patch buffers
+            int a_s[NJ], d_p[NJ];
+            bool px_in[NJ], px_st[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int rt = wid + 4 * j;
+                const int m = rt * 32 + li;
+                const int mm = m < NPIX ? m : NPIX - 1;
+                const int py = mm / C::PW, px = mm - py * C::PW;
+                a_s[j] = py * S_ROWP + lh * S_PLANE + px * 4;
+                d_p[j] = C::lds_off(py, px, lh);
+                px_st[j] = rt < NRT && m < NPIX;
+                const int gy = iy0 + py, gx = ix0 + px;
+                px_in[j] = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;      // outside the image: the main conv's zero padding
+            }
+            f32x16 hacc[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hacc[j][r] = 0.f;
+            // weights of the first conv: the standard split pack [chunk][tap][hi, lo][h][Cmid][8]; this lane's channel of the pair's 32
+            const __amdgpu_buffer_rsrc_t rs_wp = make_rsrc(p.pre_w, (unsigned)p.pre_cin * 9u * (unsigned)p.Cin * 4u);
+            const unsigned pslab = 64u * (unsigned)p.Cin, pg = 32u * (unsigned)p.Cin;
+            const unsigned vbp = (unsigned)(lh * p.Cin + pair * 32 + chan) * 16u;
+            const int pnsteps = pre_nci * 9;
+            auto load_wp = [&](int st, f32x4 (&w)[2]) {
+                const unsigned so = (unsigned)(st < pnsteps ? st : pnsteps - 1) * pslab;
+                w[0] = buf_load4(rs_wp, vbp, so);
+                w[1] = buf_load4(rs_wp, vbp, so + pg);
+            };
+            f32x4 w0[2], w1[2], w2[2];
+            load_wp(0, w0);
+            load_wp(1, w1);
+            int pst = 0;
+            for (int ci = 0; ci < pre_nci; ++ci) {
+                // the stage buffer is free (the barrier behind the previous chunk's taps / behind the main conv's last chunk)
+                pre_publish();
+                {   // next chunk of this pair -- or chunk 0 again for the next pair of this tile -- into the registers
+                    const bool more = ci + 1 < pre_nci;
+                    pre_request(more ? ci + 1 : 0, more || pair + 1 < npairs);
+                }
+                __syncthreads();
+#define BSVD_PRE_TAP(T, WCUR, WFILL)                                                                                   \
+                {                                                                                                      \
+                    __builtin_amdgcn_sched_barrier(0);                                                                 \
+                    load_wp(pst + 2, WFILL);                                                                           \
+                    f32x4 xh[NJ], xl[NJ];                                                                              \
+                    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                   \
+                        const float *ap = stg + a_s[j] + ((T) / 3) * S_ROWP + ((T) % 3) * 4;                           \
+                        xh[j] = *reinterpret_cast<const f32x4 *>(ap);                                                  \
+                        xl[j] = *reinterpret_cast<const f32x4 *>(ap + 2 * S_PLANE);                                    \
+                    }                                                                                                  \
+                    const f16x8 wh = __builtin_bit_cast(f16x8, WCUR[0]), wl = __builtin_bit_cast(f16x8, WCUR[1]);      \
+                    __builtin_amdgcn_sched_barrier(0);                                                                 \
+                    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                   \
+                        const f16x8 ah = __builtin_bit_cast(f16x8, xh[j]), al = __builtin_bit_cast(f16x8, xl[j]);      \
+                        hacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al, hacc[j], 0, 0, 0);                    \
+                        hacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah, hacc[j], 0, 0, 0);                    \
+                        hacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah, hacc[j], 0, 0, 0);                    \
+                    }                                                                                                  \
+                    ++pst;                                                                                             \
+                }
+                BSVD_PRE_TAP(0, w0, w2)
+                BSVD_PRE_TAP(1, w1, w0)
+                BSVD_PRE_TAP(2, w2, w1)
+                BSVD_PRE_TAP(3, w0, w2)
+                BSVD_PRE_TAP(4, w1, w0)
+                BSVD_PRE_TAP(5, w2, w1)
+                BSVD_PRE_TAP(6, w0, w2)
+                BSVD_PRE_TAP(7, w1, w0)
+                BSVD_PRE_TAP(8, w2, w1)
+#undef BSVD_PRE_TAP
+                __syncthreads();
+            }
+            // the main conv's weight ring does NOT ride through this function (24 registers that the first conv's accumulators need):
+            // its slabs of the next two steps are requested here, in front of the mid epilogue that covers their latency
+            load_b(bstep, b0);
+            load_b(bstep + 1, b1);
+            // bias, activation, zero outside the image, split -> the two patch buffers (chunk 2 pair + h = buffer h)
+            const float *hb = p.pre_bias + pair * 32 + 8 * lh;
+            const f32x4 bia[2][2] = {{*reinterpret_cast<const f32x4 *>(hb), *reinterpret_cast<const f32x4 *>(hb + 4)},
+                                     {*reinterpret_cast<const f32x4 *>(hb + 16), *reinterpret_cast<const f32x4 *>(hb + 20)}};
+            const float vlo = p.pre_act >= BSVD_ACT_RELU ? 0.f : -65504.f, vhi = p.pre_act == BSVD_ACT_RELU6 ? 6.f : 65504.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                // (a wave's row tile beyond the patch -- wave 3's third -- is computed like the others on a clamped pixel and not stored:
+                //  wave-uniform branches around the MFMAs cost the whole function its register allocation, and the other three waves
+                //  have a third tile anyway)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f16x8 hi, lo;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float v = hacc[j][8 * h + k] + bia[h][k >> 2][k & 3];
+                        v = px_in[j] ? __builtin_amdgcn_fmed3f(v, vlo, vhi) : 0.f;
+                        hi[k] = (_Float16)v;
+                        lo[k] = lo_keep((_Float16)__builtin_fmaf((float)hi[k], -1.0f, v));
+                    }
+                    float *dst = patch_buf + h * C::PATCH_FLOATS + d_p[j];
+                    if (px_st[j]) {
+                        *reinterpret_cast<f32x4 *>(dst) = __builtin_bit_cast(f32x4, hi);
+                        *reinterpret_cast<f32x4 *>(dst + 2 * C::PLANE) = __builtin_bit_cast(f32x4, lo);
+                    }
+                }
+            }
+        };
+        if constexpr (PREF) {
+            pre_request(0, true);          // chunk 0 of the first pair; everything else happens inside pre_pair
+        }
+        else if constexpr (HEADF) {
             const float *xin = p.x + (int64_t)f * p.x_fs;
             const int64_t plane = (int64_t)p.H * p.W;
             for (int e = tid; e < RPH * RPW; e += 256) {
@@ -854,7 +1015,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC, MIXF>())) void conv3x3_kernel
             // no MFMAs.  (Guarding the reads / MFMAs of the common loop with a wave-uniform branch instead cost every wave its
             // cross-tap schedule: 19.49 -> 19.83 ms per C1 clip.)
             // (never with the fused entry: its live loop has the head_pair barriers the staging-only loop lacks)
-            const bool wlive = (BSVD_TUNE_SKIP_DEAD && LITE && !HEADF) ? oy0 + 2 * C::MT * wm < p.Ho : true;
+            const bool wlive = (BSVD_TUNE_SKIP_DEAD && LITE && !FRONT) ? oy0 + 2 * C::MT * wm < p.Ho : true;
             if (!wlive) {
                 for (int cb = 0; cb < ncb; ++cb) {
                     ChunkSrc cn = chunk_src(cb + 1 < ncb ? cb + 1 : cb);
@@ -864,9 +1025,12 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC, MIXF>())) void conv3x3_kernel
                 }
             } else
             for (int cb = 0; cb < ncb; ++cb) {
-                if constexpr (HEADF) {
+                if constexpr (FRONT) {
                     // both patch buffers are free here (the barrier that ended chunk cb - 1): fill them with chunks cb, cb + 1
-                    if ((cb & 1) == 0) { head_pair(cb >> 1); __syncthreads(); }
+                    if ((cb & 1) == 0) {
+                        if constexpr (HEADF) head_pair(cb >> 1); else pre_pair(cb >> 1, step);
+                        __syncthreads();
+                    }
                 }
                 const float *pcur = patch_buf + (C::DBUF ? (cb & 1) * C::PATCH_FLOATS : 0);
                 [[maybe_unused]] float *pnext = patch_buf + (C::DBUF ? ((cb + 1) & 1) * C::PATCH_FLOATS : 0);
@@ -881,7 +1045,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC, MIXF>())) void conv3x3_kernel
 #define BSVD_APF_TAP(T, HC, LC, HN, LN, BCUR, BFILL, SNEW, SOLD)                                                           \
                 {                                                                                                        \
                     if constexpr (!(BSVD_ABL & 4)) load_b(step + 2 < nsteps ? step + 2 : nsteps - 1, BFILL);             \
-                    if constexpr (C::DBUF && !HEADF && !(BSVD_ABL & 2)) slice_load(cn, (T) * C::ROWS_PER_SLICE, SNEW);    /* rows >= PH: zeros */ \
+                    if constexpr (C::DBUF && !FRONT && !(BSVD_ABL & 2)) slice_load(cn, (T) * C::ROWS_PER_SLICE, SNEW);    /* rows >= PH: zeros */ \
                     __builtin_amdgcn_sched_barrier(0);                                                                   \
                     pass(LC, BCUR, 0);                                                      /* hi(w) x lo(x) */           \
                     __builtin_amdgcn_sched_barrier(0);                                                                   \
@@ -897,7 +1061,7 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC, MIXF>())) void conv3x3_kernel
                         load_hi(pcur, ((T) + 1) / 3, ((T) + 1) % 3, HN);                                                 \
                         __builtin_amdgcn_sched_barrier(0);                                                               \
                     }                                                                                                    \
-                    if constexpr (C::DBUF && !HEADF && !(BSVD_ABL & 2))                                                  \
+                    if constexpr (C::DBUF && !FRONT && !(BSVD_ABL & 2))                                                  \
                         if ((T) >= BSVD_TUNE_D && (T) <= C::NSLICE - 1 + BSVD_TUNE_D) slice_store(pnext, ((T) - BSVD_TUNE_D) * C::ROWS_PER_SLICE, SOLD); \
                     ++step;                                                                                              \
                 }
@@ -928,9 +1092,12 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC, MIXF>())) void conv3x3_kernel
             }
         } else
         for (int cb = 0; cb < ncb; ++cb) {
-            if constexpr (HEADF) {
+            if constexpr (FRONT) {
                 // both patch buffers are free here (the barrier that ended chunk cb - 1): fill them with chunks cb, cb + 1
-                if ((cb & 1) == 0) { head_pair(cb >> 1); __syncthreads(); }
+                if ((cb & 1) == 0) {
+                    if constexpr (HEADF) head_pair(cb >> 1); else pre_pair(cb >> 1, step);
+                    __syncthreads();
+                }
             }
             const float *pcur = patch_buf + (C::DBUF ? (cb & 1) * C::PATCH_FLOATS : 0);
             float *pnext = patch_buf + (C::DBUF ? ((cb + 1) & 1) * C::PATCH_FLOATS : 0);
@@ -950,9 +1117,9 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC, MIXF>())) void conv3x3_kernel
                     f32x4 a[C::MT][2];                                                                         \
                     load_a(pcur, ky, (KX), a);                                                                 \
                     load_b(step + C::RING - 1 < nsteps ? step + C::RING - 1 : nsteps - 1, BFILL);              \
-                    if constexpr (C::DBUF && !HEADF) slice_load(cn, tap * C::ROWS_PER_SLICE, SNEW);   /* rows >= PH: zeros */ \
+                    if constexpr (C::DBUF && !FRONT) slice_load(cn, tap * C::ROWS_PER_SLICE, SNEW);   /* rows >= PH: zeros */ \
                     mfma32(a, BCUR);                                                                           \
-                    if constexpr (C::DBUF && !HEADF)                                                           \
+                    if constexpr (C::DBUF && !FRONT)                                                           \
                         if (tap >= BSVD_TUNE_D && tap <= C::NSLICE - 1 + BSVD_TUNE_D) slice_store(pnext, (tap - BSVD_TUNE_D) * C::ROWS_PER_SLICE, SOLD); \
                     ++step;                                                                                    \
                 }
@@ -1375,13 +1542,13 @@ __global__ __launch_bounds__(256, (occ_of<C, PREC, MIXF>())) void conv3x3_kernel
     TL(3);
 }
 
-template <class C, bool FAST, int PREC, bool MIXF = false, bool HEADF = false>
+template <class C, bool FAST, int PREC, bool MIXF = false, bool HEADF = false, bool PREF = false>
 static int launch_cfg(const ConvParams &pin, hipStream_t stream, char *name = nullptr, int name_len = 0)
 {
     if (name) {      // dry run: report the instantiation bsvd_conv3x3 would launch (used by bench.py's per-kernel timing)
-        snprintf(name, name_len, "conv3x3_kernel<%d,%d,%d,%d,%d>[%s]%s%s%s", C::MT, C::NT, C::WM, C::WN, C::STRIDE,
+        snprintf(name, name_len, "conv3x3_kernel<%d,%d,%d,%d,%d>[%s]%s%s%s%s", C::MT, C::NT, C::WM, C::WN, C::STRIDE,
                  PREC == 1 ? "f16x3" : "f32", FAST ? (MIXF ? "[fold8]" : "") : "[generic]", pin.y_planar_ch > 0 ? "[planar out]" : "",
-                 HEADF ? "[fused entry]" : "");
+                 HEADF ? "[fused entry]" : "", PREF ? "[fused pair]" : "");
         return 0;
     }
     ConvParams p = pin;
@@ -1393,10 +1560,12 @@ static int launch_cfg(const ConvParams &pin, hipStream_t stream, char *name = nu
     const int64_t nblk = (int64_t)p.frames * p.nty * p.ntx * p.nct;
     if (nblk <= 0 || nblk > 0x7fffffff) { set_error("bsvd_conv3x3: grid of %lld workgroups", (long long)nblk); return -1; }
     static std::atomic<int> granted[MAX_DEVICES];
-    constexpr int LDS = C::LDS_BYTES + (HEADF ? (C::TH + 4) * (C::TW + 4) * 16 : 0);      // + the raw input patch of the fused entry
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv3x3_kernel<C, FAST, PREC, MIXF, HEADF>), LDS, granted);
+    // + the raw input patch of the fused entry / the first conv's staged input chunk of a fused pair (20 rows x 1280 B)
+    constexpr int LDS = C::LDS_BYTES + (HEADF ? (C::TH + 4) * (C::TW + 4) * 16 : 0) +
+                        (PREF ? (C::TH + 4) * (((C::TW + 4) * 64 + 255) / 256 * 256) : 0);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv3x3_kernel<C, FAST, PREC, MIXF, HEADF, PREF>), LDS, granted);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((conv3x3_kernel<C, FAST, PREC, MIXF, HEADF>), dim3((unsigned)nblk), dim3(256), LDS, stream, p);
+    hipLaunchKernelGGL((conv3x3_kernel<C, FAST, PREC, MIXF, HEADF, PREF>), dim3((unsigned)nblk), dim3(256), LDS, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -1407,6 +1576,14 @@ static int launch_headf(const ConvParams &p, hipStream_t stream, char *name, int
 {
     if constexpr (C::QPL) return launch_cfg<C, true, 1, false, true>(p, stream, name, name_len);
     else { set_error("bsvd_conv3x3: this build (BSVD_TUNE_QPL without bit 2) has no fused-entry kernel"); return -18; }
+}
+
+// the fused pair exists for the quad-planar 32-channel-wave tiles (the 64-channel layers' tile and the exit tile)
+template <class C>
+static int launch_pref(const ConvParams &p, hipStream_t stream, char *name, int name_len)
+{
+    if constexpr (C::QPL) return launch_cfg<C, true, 1, false, false, true>(p, stream, name, name_len);
+    else { set_error("bsvd_conv3x3: this build (BSVD_TUNE_QPL) has no fused-pair kernel"); return -20; }
 }
 
 static bool fast_ok(const ConvParams &p, bool honour_force_generic = true)
@@ -1458,7 +1635,12 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
         }
         if (p.y_planar_ch > 0) {         // network exit: 256 px x 32 ch tiles, planar fp32 epilogue
             if (stride != 1 || p.fold != 0 || p.Cout > 32) { set_error("bsvd_conv3x3: planar split output needs stride 1, fold 0, Cout <= 32"); return -16; }
+            if (p.pre_w) return launch_pref<ConvCfg<2, 1, 4, 1, 1, 3>>(p, stream, name, name_len);       // fused pair: out0 -> exit
             return launch_cfg<ConvCfg<2, 1, 4, 1, 1, 3>, true, 1>(p, stream, name, name_len);
+        }
+        if (p.pre_w) {                   // fused 64-channel pair (validated by the ABI layer): the narrow tile with the first conv inside
+            if (stride != 1 || p.fold != 0 || p.Cout > 64 || (p.Cin & 31)) { set_error("bsvd_conv3x3: fused pair needs stride 1, fold 0, Cin %% 32 == 0, Cout <= 64"); return -20; }
+            return launch_pref<ConvCfg<4, 1, 2, 2, 1, 3>>(p, stream, name, name_len);
         }
         if (stride == 2) {
             if constexpr (BSVD_TUNE_S2_SPLIT == 1) return launch_cfg<ConvCfg<1, 2, 2, 2, 2, 3, true>, true, 1>(p, stream, name, name_len);

@@ -992,7 +992,7 @@ static bool wino_code_known(int m)
 {
     if (m == 2 || m == 6 || m == 42 || m == 46) return true;
 #ifdef BSVD_MEASURE
-    if (m == 4 || m == 12 || m == 14 || m == 22 || m == 32 || m == 36 || m == 52 || m == 62) return true;
+    if (m == 4 || m == 12 || m == 22 || m == 32 || m == 36 || m == 52 || m == 62) return true;      // (14 = F(4,3) all positions per wave: fails parity, not offered)
 #endif
     return false;
 }
@@ -1002,7 +1002,7 @@ const char *wino_unsupported(const ConvParams &p, int stride)
     if (p.prec != 1) return "dtype must be BSVD_F16X3";
     if (!wino_code_known(p.wino_m))
 #ifdef BSVD_MEASURE
-        return "wino_m must be 2 or 6 (42 / 46: never the half-height tile; measurement build: 4, 12, 14, 22, 32, 36, 52, 62)";
+        return "wino_m must be 2 or 6 (42 / 46: never the half-height tile; measurement build: 4, 12, 22, 32, 36, 52, 62)";
 #else
         return "wino_m must be 2 or 6 (42 / 46: the same forms, never on the half-height tile); the other codes exist in measurement builds (-DBSVD_MEASURE) only";
 #endif

@@ -35,14 +35,26 @@ def head_fusable(inc0, inc3, precision):
             and not inc3.tsm and inc3.epilogue == EPI_PLAIN and inc0.act == inc3.act)
 
 
+def pair_fusable(a, b, precision):
+    """Can two consecutive plain stride-1 convs a -> b run as ONE launch (BsvdConvArgs.pre_w_packed)?  Split-fp16 mode, both without
+    temporal shift, a's (padded) output = b's input in whole 32-channel pairs, b with <= 64 output channels and a PLAIN or RESID
+    epilogue (the planar exit included).  The 64-channel full-resolution pairs of a DenBlock: OutputCvBlock out0 -> out3 and, where the
+    block has no planar entry, InputCvBlock inc0 -> inc3 (bsvd_arch.py:194-226, 287-306)."""
+    return (precision == "f16x3" and a.stride == 1 and b.stride == 1 and not a.tsm and not b.tsm and a.epilogue == EPI_PLAIN
+            and b.epilogue in (EPI_PLAIN, EPI_RESID) and a.cin_pad % 16 == 0 and a.cin > 4 and a.cout_pad == b.cin_pad
+            and b.cin_pad % 32 == 0 and b.cout_pad <= 64)
+
+
 # Forms of the wide layers: "direct" (3-pass implicit GEMM), "wino2" (1-D Winograd F(2,3) along x; default of arch.BSVD), "wino6" (F(6,3)),
 # "wino26" (F(2,3) on the 128 -> 128 layers, F(6,3) on the wider ones).  That is all the product library contains.
 WIDE_CONV = ("direct", "wino2", "wino6", "wino26")
 # Measurement / test variants of the same arithmetic -- accepted only when the loaded library is a MEASUREMENT build (tools/build_measure.sh,
 # selected with BSVD_HIP_LIB; bsvd_build_info() & BUILD_MEASURE): name -> (F(m,3), BsvdConvArgs.wino_m).  "wino4" F(4,3); "wino2h" / "wino6h"
 # always the 8-row tile; "wino2n" one tile per workgroup whatever the grid, "wino2p" the persistent form; "wino2s" 4-wave workgroups;
-# "wino2b" / "wino4b" the all-positions-per-wave kernel (conv3x3_wino.hip).  DESIGN.md 4.1d records each of them as slower.
-MEASURE_WIDE_CONV = {"wino4": (4, 4), "wino2b": (2, 12), "wino4b": (4, 14), "wino2s": (2, 22), "wino2h": (2, 32), "wino6h": (6, 36),
+# "wino2b" the all-positions-per-wave kernel (conv3x3_wino.hip).  DESIGN.md 4.1d records each of them as slower.
+# (The all-positions kernel's F(4,3) instantiation -- wino_m 14, 264 B of scratch -- was never parity-tested in round 4 and fails against the
+#  oracle on its first test in round 5: it is not offered.)
+MEASURE_WIDE_CONV = {"wino4": (4, 4), "wino2b": (2, 12), "wino2s": (2, 22), "wino2h": (2, 32), "wino6h": (6, 36),
                      "wino2n": (2, 52), "wino2p": (2, 62)}
 _FORMS = {"direct": (0, 0), "wino2": (2, 2), "wino6": (6, 6), "wino26": (6, 6)}
 
@@ -78,7 +90,7 @@ class PackedNet:
     """Device-resident pre-packed weights of every layer (one-time transform of the state_dict,
     cf. BSVD.load, bsvd_arch.py:462-474): {spec.key: (w_packed, bias_packed)}."""
 
-    def __init__(self, net, state, device, precision="fp32", wide_conv="direct", wino_min_cin=None):
+    def __init__(self, net, state, device, precision="fp32", wide_conv="direct", wino_min_cin=None, fuse_pairs=False):
         lib = require_hip()
         if not wide_conv_known(wide_conv, lib):
             if wide_conv in MEASURE_WIDE_CONV:
@@ -147,6 +159,17 @@ class PackedNet:
                                                 sp0.cout_pad, hw.data_ptr(), hb.data_ptr(), _stream_ptr())
                 _lib.check(rc, "bsvd_pack_head_weights(%s)" % sp0.key)
                 self.head[sp3.key] = (hw, hb, sp0)
+            # fused 64-channel pairs (BsvdConvArgs.pre_w_packed), keyed by the SECOND conv: both layers keep their ordinary packs (the
+            # first conv's is handed over as pre_w_packed / pre_bias), so a fused and an unfused launch read the same weights
+            self.pairs = {}
+            if fuse_pairs:
+                for blk in (getattr(net, "temp1", None), getattr(net, "temp2", None)):
+                    if blk is None:
+                        continue
+                    for na, nb in (("inc0", "inc3"), ("out0", "out3")):
+                        if na in blk and nb in blk and blk[nb].key not in self.head and pair_fusable(blk[na], blk[nb], precision) \
+                                and self.tensors[blk[na].key][0] is not None and self.tensors[blk[nb].key][0] is not None:
+                            self.pairs[blk[nb].key] = blk[na]
             # The packed tensors are read from whatever stream a later forward runs on (ClipPipeline's compute stream,
             # the A/B streams of streaming_forward, a graph replay): finish the one-time pack here so no consumer can see
             # half-packed weights.  (The w/b temporaries are consumed by kernels queued on this stream.)
@@ -269,6 +292,23 @@ class HipExecutor:
         """True if block ``S``'s entry pair inc0 -> inc3 runs as one launch (see head_fusable)"""
         return "inc3" in S and S["inc3"].key in getattr(self.packed, "head", {})
 
+    def fuse_pair(self, S, na, nb):
+        """True if block ``S``'s layers na -> nb run as one launch (see pair_fusable; PackedNet(fuse_pairs=True))"""
+        return nb in S and getattr(self.packed, "pairs", {}).get(S[nb].key) is S.get(na)
+
+    def conv_pair_fused(self, spa, spb, x, extra=None, extra_pstride=0, extra_cstride=1, y_planar=None, out=None):
+        """Two plain convs in one launch: x NHWC split16 -> epilogue(act(conv(act(conv(x, spa)), spb))); the tensor between them
+        never exists in HBM."""
+        a, y = self.build_args(spb, x, None, None, extra, extra_pstride, extra_cstride, False, y_planar, out, pre=spa)
+        if self.record_variants:
+            buf = ctypes.create_string_buffer(96)
+            _lib.check(self.lib.bsvd_conv3x3_variant(ctypes.byref(a), buf, 96), "bsvd_conv3x3_variant(%s)" % spb.key)
+            self.last_variant = buf.value.decode()
+        rc = self.lib.bsvd_conv3x3(ctypes.byref(a), _stream_ptr())
+        _lib.check(rc, "bsvd_conv3x3(%s + %s)" % (spa.key, spb.key))
+        self.launches += 1
+        return y
+
     def conv_head_fused(self, sp0, sp3, x, out=None):
         """InputCvBlock in one launch: x planar [T,C,H,W] -> act(conv(act(conv(x, sp0)), sp3)) as NHWC split16; the
         intermediate tensor never exists in HBM."""
@@ -287,7 +327,7 @@ class HipExecutor:
         return _lib.BsvdConvArgs
 
     def build_args(self, sp, x, halo_prev=None, halo_next=None, extra=None, extra_pstride=0, extra_cstride=1,
-                   x_planar=False, y_planar=None, out=None, alloc=True, head=None, shared_chip=False):
+                   x_planar=False, y_planar=None, out=None, alloc=True, head=None, shared_chip=False, pre=None):
         """Validates one fused layer and fills its ``BsvdConvArgs``; returns (args, y).  ``alloc=False`` leaves ``y`` (and
         ``args.y``) unset for the caller to supply per launch (the stream plan's exit layer).  ``shared_chip``: the launch runs
         beside another graph branch -- a Winograd layer then keeps its full tile whatever the grid (same bits; CUs its grid
@@ -314,6 +354,13 @@ class HipExecutor:
                 raise ValueError("%s: planar input needs a plain stride-1 layer with <= 4 input channels" % sp.key)
             a.x_planar_ch = C
             a.x_frame_stride = C * H * W
+        elif pre is not None:
+            T, H, W, cin_pad = x.shape
+            if self.packed.pairs.get(sp.key) is not pre or cin_pad != pre.cin_pad:
+                raise ValueError("%s: fused pair expects the %d-channel input of %s" % (sp.key, pre.cin_pad, pre.key))
+            pw, pb = self.packed.tensors[pre.key]
+            a.x_frame_stride = H * W * cin_pad
+            a.pre_w_packed, a.pre_bias, a.pre_cin, a.pre_act = pw.data_ptr(), pb.data_ptr(), pre.cin_pad, _lib.ACT[pre.act]
         else:
             T, H, W, cin_pad = x.shape
             if cin_pad != sp.cin_pad:

@@ -41,6 +41,33 @@ def _fused_head(ex, S):
     return bool(fn and fn(S))
 
 
+def _fused_pair(ex, S, na, nb):
+    """do layers na -> nb of block S run as one launch (engine.pair_fusable)?"""
+    fn = getattr(ex, "fuse_pair", None)
+    return bool(fn and fn(S, na, nb))
+
+
+def _inc(ex, S, x, x_planar):
+    """InputCvBlock (bsvd_arch.py:194-226): fused entry (planar input), fused pair (NHWC input) or two launches"""
+    if x_planar and _fused_head(ex, S):
+        return ex.conv_head_fused(S["inc0"], S["inc3"], x)          # InputCvBlock in one launch (engine.head_fusable)
+    if not x_planar and _fused_pair(ex, S, "inc0", "inc3"):
+        return ex.conv_pair_fused(S["inc0"], S["inc3"], x)
+    a = ex.conv(S["inc0"], x, x_planar=True) if x_planar else ex.conv(S["inc0"], x)
+    return ex.conv(S["inc3"], a)
+
+
+def _outc(ex, S, w, base, eps, ecs, y_planar):
+    """OutputCvBlock + the block's residual (bsvd_arch.py:287-306, 408-414): one launch for the pair, or two"""
+    kw = dict(extra=base, extra_pstride=eps, extra_cstride=ecs)
+    if y_planar is not None:
+        kw["y_planar"] = y_planar
+    if _fused_pair(ex, S, "out0", "out3"):
+        return ex.conv_pair_fused(S["out0"], S["out3"], w, **kw)
+    o = ex.conv(S["out0"], w)
+    return ex.conv(S["out3"], o, **kw)
+
+
 def denblock_clip(ex, S, x, halo_fn=None, x_planar=False, y_planar=None):
     """One DenBlock over a clip.  x: [T,H,W,cin_pad] NHWC (or planar [T,C,H,W] with x_planar).
     halo_fn(spec, x) -> (Halo|None, Halo|None) supplies the neighbour shards' boundary slices when the clip
@@ -65,12 +92,7 @@ def denblock_clip(ex, S, x, halo_fn=None, x_planar=False, y_planar=None):
         hp, hn = halo_fn(sp, v)
         return ex.conv(sp, v, halo_prev=hp, halo_next=hn)
 
-    if x_planar and _fused_head(ex, S):
-        x0 = ex.conv_head_fused(S["inc0"], S["inc3"], x)          # InputCvBlock in one launch (engine.head_fusable)
-    else:
-        a = ex.conv(S["inc0"], x, x_planar=True) if x_planar else ex.conv(S["inc0"], x)
-        x0 = ex.conv(S["inc3"], a)
-        del a
+    x0 = _inc(ex, S, x, x_planar)
     d = ex.conv(S["down0"], x0)
     x1 = tsm("d0c2", tsm("d0c1", d))
     d = ex.conv(S["down1"], x1)
@@ -83,12 +105,8 @@ def denblock_clip(ex, S, x, halo_fn=None, x_planar=False, y_planar=None):
     v = tsm("u1c2", tsm("u1c1", v))
     w = ex.conv(S["up1"], v, extra=x0, extra_pstride=x0.shape[-1])        # PixelShuffle + skip2
     del v, x0
-    o = ex.conv(S["out0"], w)
-    del w
     eps, ecs = _base_strides(x, x_planar)                                 # residual vs. the block input
-    if y_planar is not None:
-        return ex.conv(S["out3"], o, extra=x, extra_pstride=eps, extra_cstride=ecs, y_planar=y_planar)
-    return ex.conv(S["out3"], o, extra=x, extra_pstride=eps, extra_cstride=ecs)
+    return _outc(ex, S, w, x, eps, ecs, y_planar)
 
 
 def bsvd_clip(ex, net, x, halo_fn=None, x_planar=False, y_planar=None):
@@ -175,10 +193,7 @@ class _DenBlockStream:
         self.skip_in.push(x)
         x0 = None
         if x is not None:
-            if x_planar and _fused_head(ex, S):
-                x0 = ex.conv_head_fused(S["inc0"], S["inc3"], x)
-            else:
-                x0 = ex.conv(S["inc3"], ex.conv(S["inc0"], x, x_planar=True) if x_planar else ex.conv(S["inc0"], x))
+            x0 = _inc(ex, S, x, x_planar)
         self.skip_x0.push(x0)
         d = None if x0 is None else ex.conv(S["down0"], x0)
         x1 = self._pair(ex, "d0c1", "d0c2", d)
@@ -195,10 +210,7 @@ class _DenBlockStream:
         if w is None:
             return None
         eps, ecs = _base_strides(base, x_planar)
-        o = ex.conv(S["out0"], w)
-        if y_planar is not None:
-            return ex.conv(S["out3"], o, extra=base, extra_pstride=eps, extra_cstride=ecs, y_planar=y_planar)
-        return ex.conv(S["out3"], o, extra=base, extra_pstride=eps, extra_cstride=ecs)
+        return _outc(ex, S, w, base, eps, ecs, y_planar)
 
 
 class StreamPipeline:

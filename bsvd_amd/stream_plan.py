@@ -89,12 +89,27 @@ class _Recorder:
         T = x.shape[0]
         if T != o.shape[0]:
             o = o[:T]                 # the last chunk of a clip may be shorter
-        self.rec.append((sp, x, halo_prev, halo_next, extra, extra_pstride, extra_cstride, x_planar, y_planar, o))
+        self.rec.append((sp, x, halo_prev, halo_next, extra, extra_pstride, extra_cstride, x_planar, y_planar, o, None, None))
         return o
 
     def fuse_head(self, S):
         fn = getattr(self.eng.ex, "fuse_head", None)
         return bool(fn and fn(S))
+
+    def fuse_pair(self, S, na, nb):
+        fn = getattr(self.eng.ex, "fuse_pair", None)
+        return bool(fn and fn(S, na, nb))
+
+    def conv_pair_fused(self, spa, spb, x, extra=None, extra_pstride=0, extra_cstride=1, y_planar=None, out=None):
+        """a fused pair of plain convs as ONE recorded launch writing spb's ring (spa's ring does not exist)"""
+        ring = self.eng.rings[spb.key]
+        n = self.count.get(spb.key, 0)
+        self.count[spb.key] = n + 1
+        o = ring[n % len(ring)]
+        if x.shape[0] != o.shape[0]:
+            o = o[:x.shape[0]]
+        self.rec.append((spb, x, None, None, extra, extra_pstride, extra_cstride, False, y_planar, o, None, spa))
+        return o
 
     def conv_head_fused(self, sp0, sp3, x, out=None):
         """the fused entry pair as ONE recorded launch writing inc3's ring (inc0's ring stays unused)"""
@@ -104,7 +119,7 @@ class _Recorder:
         o = ring[n % len(ring)]
         if x.shape[0] != o.shape[0]:
             o = o[:x.shape[0]]
-        self.rec.append((sp3, x, None, None, None, 0, 1, True, None, o, sp0))
+        self.rec.append((sp3, x, None, None, None, 0, 1, True, None, o, sp0, None))
         return o
 
     def take(self):
@@ -151,7 +166,13 @@ class StreamEngine:
         ring("input", (n, in_ch, H, W), 10)
         exit_key = net.temp2["out3"].key
         fuse = getattr(ex, "fuse_head", None)
-        fused_entry = net.temp1["inc0"].key if (fuse and fuse(net.temp1)) else None     # its output never exists (engine.head_fusable)
+        fused_away = {net.temp1["inc0"].key} if (fuse and fuse(net.temp1)) else set()     # their outputs never exist (engine.head_fusable / pair_fusable)
+        fusep = getattr(ex, "fuse_pair", None)
+        if fusep:
+            for blk in (net.temp1, net.temp2):
+                for na, nb in (("inc0", "inc3"), ("out0", "out3")):
+                    if fusep(blk, na, nb):
+                        fused_away.add(blk[na].key)
         for blk in (net.temp1, net.temp2):
             h, w = H, W
             for name, sp in blk.items():
@@ -164,7 +185,7 @@ class StreamEngine:
                     h, w = ho, wo
                 if sp.key == exit_key:          # planar [n, out_ch, H, W]: what the caller gets a copy of
                     shape = (n, sp.cout, ho, wo)
-                if sp.key == fused_entry:
+                if sp.key in fused_away:
                     continue
                 ring(sp.key, shape, ring_depth(name, blk is net.temp1 and name == "out3", sp.key == exit_key))
         self.t1 = _DenBlockStream(net.temp1)
@@ -245,7 +266,7 @@ class StreamEngine:
             if self.hip:
                 plan.args = (self.ex.lib_args_type() * max(plan.n, 1))()
                 for i, r in enumerate(rec):
-                    plan.args[i], _ = self.ex.build_args(*r[:9], out=r[9], head=r[10] if len(r) > 10 else None, shared_chip=shared_chip)
+                    plan.args[i], _ = self.ex.build_args(*r[:9], out=r[9], head=r[10], shared_chip=shared_chip, pre=r[11])
             self.plans[sig] = plan
         return y, sig, plan
 
@@ -254,8 +275,11 @@ class StreamEngine:
         """plain executor (CPU tests): layer by layer, in order"""
         for r in plan.rec:
             sp, x, hp, hn, extra, eps, ecs, xpl, ypl, o = r[:10]
-            if len(r) > 10:
+            if r[10] is not None:
                 self.ex.conv_head_fused(r[10], sp, x, out=o)
+                continue
+            if r[11] is not None:
+                self.ex.conv_pair_fused(r[11], sp, x, extra=extra, extra_pstride=eps, extra_cstride=ecs, y_planar=ypl, out=o)
                 continue
             self.ex.conv(sp, x, halo_prev=hp, halo_next=hn, extra=extra, extra_pstride=eps, extra_cstride=ecs,
                          x_planar=xpl, y_planar=ypl, out=o)

@@ -140,6 +140,21 @@ typedef struct BsvdConvArgs {
      * wide direct-form BSVD_F16X3 layer takes the 128-accumulator tile instead of the 64-accumulator one.  Both tiles compute the
      * same bits; the field replaces an environment variable the library used to read once per process. */
     int32_t fat_min_wgs;
+    /* Fused pair of plain stride-1 convs (ABI v10, BSVD_F16X3 only): with pre_w_packed != NULL the launch computes
+     *     t = pre_act(conv3x3(x, pre_w) + pre_bias)            (pre_cin -> Cin channels, zero outside the image)
+     *     y = epilogue(act(conv3x3(t, w_packed) + bias))       (Cin -> Cout channels; PLAIN, RESID or the planar exit)
+     * in ONE kernel: every tile computes the first conv on its own 18 x 18 patch (full K = 9 pre_cin on the matrix cores, the input
+     * patch staged chunk by chunk through LDS) a pair of 16-channel chunks at a time, straight into the LDS patch of the second
+     * conv; the Cin-channel tensor t never exists in HBM (1.33 GB written + read per 10-frame 540x960 clip at 64 channels).  The
+     * price is the halo: 324 patch pixels in 11 MFMA row tiles per 256 output pixels = 1.375x the first conv's MFMAs.  x is the first
+     * conv's NHWC input [frames][H][W][pre_cin] (x_frame_stride its frame stride); pre_w_packed = bsvd_pack_weights(dtype
+     * BSVD_F16X3) of the first conv (pre_cin -> Cin), pre_bias its bias_packed [Cin].  Both convs: OutputCvBlock / InputCvBlock,
+     * bsvd_arch.py:194-226, 287-306.  Needs pre_cin % 16 == 0, Cin % 32 == 0, Cout <= 64, stride 1, fold 0, no planar INPUT, no
+     * head_w_packed / w_wino_packed; anything else returns -20 with the reason.  Per output the arithmetic of both convs is the
+     * stand-alone kernels': fused == unfused bit for bit. */
+    const void *pre_w_packed;
+    const void *pre_bias;
+    int32_t pre_cin, pre_act;
 } BsvdConvArgs;
 
 int bsvd_abi_version(void);
