@@ -424,12 +424,15 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
     const int nb0 = n0 + wn * (C::NT * 32) + chan;               // output channel whose weights this lane loads for nt = 0 (+32 per nt)
 
     f32x16 acc[C::MT][C::NT];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt)
+        for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt)
+            for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    };
+    if constexpr (!PREF) zero_acc();      // (fused pair: after the first conv -- 64 registers of zeros would ride through it otherwise)
 
     // pixel fragments of tap (ky, KX): immediate offsets from the lane's base in both layouts
     // (kx is a literal in the fast path's unrolled taps and folds into the instruction's offset field; the generic path passes
@@ -795,69 +798,82 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
                 if constexpr (PREF) if (inp) *reinterpret_cast<f32x4 *>(stg + lo) = phold[i];
             }
         };
-        [[maybe_unused]] auto pre_pair = [&](int pair, int bstep) {
+        // The first conv for ALL Cin (<= 64) channels of the second conv's K in ONE pass over the staged input (every input chunk fetched
+        // once per tile): the accumulators of both 32-channel pairs (2 x NJ MFMA tiles per wave) live in registers; pair 0 is written to
+        // the patch buffers right away, pair 1 waits in its registers while the main conv consumes pair 0 (its accumulators are the
+        // only other large register block then) and is written at the pair boundary.  (First version of the round: one pass per pair --
+        // the input staged twice, 3.77 GB fetched per launch for a 1.33 GB input, PMC r05b; this form: r05c.)
+        constexpr int PNPIX = C::PH * C::PW, PNRT = (PNPIX + 31) / 32, PNJ = (PNRT + 3) / 4;     // 324 pixels, 11 row tiles, <= 3 per wave
+        [[maybe_unused]] f32x16 pacc[PREF ? 2 : 1][PREF ? PNJ : 1];
+        // this wave's row tiles wid, wid + 4, ...: lane pixel -> offset in the stage buffer / the patch buffers.  (A wave's row tile
+        // beyond the patch -- wave 3's third -- is computed like the others on a clamped pixel and not stored: wave-uniform branches
+        // around the MFMAs cost the whole function its register allocation, and the other three waves have a third tile anyway.)
+        [[maybe_unused]] auto pre_geom = [&](int j, int &a_s, int &d_p, bool &px_in, bool &px_st) {
+            const int rt = wid + 4 * j;
+            const int m = rt * 32 + li;
+            const int mm = m < PNPIX ? m : PNPIX - 1;
+            const int py = mm / C::PW, px = mm - py * C::PW;
+            a_s = py * S_ROWP + lh * S_PLANE + px * 4;
+            d_p = C::lds_off(py, px, lh);
+            px_st = rt < PNRT && m < PNPIX;
+            const int gy = iy0 + py, gx = ix0 + px;
+            px_in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;      // outside the image: the main conv's zero padding
+        };
+        [[maybe_unused]] auto pre_all = [&]() {
             static_assert(!PREF || (C::QPL && C::STRIDE == 1 && C::DBUF && PREC == 1 && C::NT == 1), "fused pair: quad-planar stride-1 split tile, 32-channel wave tiles");
-            constexpr int NPIX = C::PH * C::PW, NRT = (NPIX + 31) / 32, NJ = (NRT + 3) / 4;     // 324 pixels, 11 row tiles, <= 3 per wave
-            const int npairs = p.Cin >> 5;
-            // this wave's row tiles wid, wid + 4, ...: lane pixel -> offset in the stage buffer / the patch buffers
-            int a_s[NJ], d_p[NJ];
-            bool px_in[NJ], px_st[NJ];
+            int a_s[PNJ];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int rt = wid + 4 * j;
-                const int m = rt * 32 + li;
-                const int mm = m < NPIX ? m : NPIX - 1;
-                const int py = mm / C::PW, px = mm - py * C::PW;
-                a_s[j] = py * S_ROWP + lh * S_PLANE + px * 4;
-                d_p[j] = C::lds_off(py, px, lh);
-                px_st[j] = rt < NRT && m < NPIX;
-                const int gy = iy0 + py, gx = ix0 + px;
-                px_in[j] = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;      // outside the image: the main conv's zero padding
-            }
-            f32x16 hacc[NJ];
+            for (int j = 0; j < PNJ; ++j) { int d; bool b1_, b2_; pre_geom(j, a_s[j], d, b1_, b2_); }
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hacc[j][r] = 0.f;
-            // weights of the first conv: the standard split pack [chunk][tap][hi, lo][h][Cmid][8]; this lane's channel of the pair's 32
+                for (int j = 0; j < PNJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pacc[n][j][r] = 0.f;
+            // weights of the first conv: the standard split pack [chunk][tap][hi, lo][h][Cmid][8]; this lane's channel of each 32-channel
+            // pair (a second pair beyond Cin: the out-of-range sentinel = zero weights, its tiles are never stored)
             const __amdgpu_buffer_rsrc_t rs_wp = make_rsrc(p.pre_w, (unsigned)p.pre_cin * 9u * (unsigned)p.Cin * 4u);
             const unsigned pslab = 64u * (unsigned)p.Cin, pg = 32u * (unsigned)p.Cin;
-            const unsigned vbp = (unsigned)(lh * p.Cin + pair * 32 + chan) * 16u;
+            unsigned vbp[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) vbp[n] = n * 32 < p.Cin ? (unsigned)(lh * p.Cin + n * 32 + chan) * 16u : BSVD_OOB;
             const int pnsteps = pre_nci * 9;
-            auto load_wp = [&](int st, f32x4 (&w)[2]) {
+            auto load_wp = [&](int st, f32x4 (&w)[2][2]) {
                 const unsigned so = (unsigned)(st < pnsteps ? st : pnsteps - 1) * pslab;
-                w[0] = buf_load4(rs_wp, vbp, so);
-                w[1] = buf_load4(rs_wp, vbp, so + pg);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    w[n][0] = buf_load4(rs_wp, vbp[n], so);
+                    w[n][1] = buf_load4(rs_wp, vbp[n], so + pg);
+                }
             };
-            f32x4 w0[2], w1[2], w2[2];
+            f32x4 w0[2][2], w1[2][2], w2[2][2];
             load_wp(0, w0);
             load_wp(1, w1);
             int pst = 0;
             for (int ci = 0; ci < pre_nci; ++ci) {
-                // the stage buffer is free (the barrier behind the previous chunk's taps / behind the main conv's last chunk)
+                // the stage buffer is free (the barrier behind the previous chunk's taps)
                 pre_publish();
-                {   // next chunk of this pair -- or chunk 0 again for the next pair of this tile -- into the registers
-                    const bool more = ci + 1 < pre_nci;
-                    pre_request(more ? ci + 1 : 0, more || pair + 1 < npairs);
-                }
+                pre_request(ci + 1, ci + 1 < pre_nci);       // the next chunk into the registers (behind the last one: nothing)
                 __syncthreads();
 #define BSVD_PRE_TAP(T, WCUR, WFILL)                                                                                   \
                 {                                                                                                      \
                     __builtin_amdgcn_sched_barrier(0);                                                                 \
                     load_wp(pst + 2, WFILL);                                                                           \
-                    f32x4 xh[NJ], xl[NJ];                                                                              \
-                    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                   \
+                    f32x4 xh[PNJ], xl[PNJ];                                                                            \
+                    _Pragma("unroll") for (int j = 0; j < PNJ; ++j) {                                                  \
                         const float *ap = stg + a_s[j] + ((T) / 3) * S_ROWP + ((T) % 3) * 4;                           \
                         xh[j] = *reinterpret_cast<const f32x4 *>(ap);                                                  \
                         xl[j] = *reinterpret_cast<const f32x4 *>(ap + 2 * S_PLANE);                                    \
                     }                                                                                                  \
-                    const f16x8 wh = __builtin_bit_cast(f16x8, WCUR[0]), wl = __builtin_bit_cast(f16x8, WCUR[1]);      \
                     __builtin_amdgcn_sched_barrier(0);                                                                 \
-                    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                   \
-                        const f16x8 ah = __builtin_bit_cast(f16x8, xh[j]), al = __builtin_bit_cast(f16x8, xl[j]);      \
-                        hacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al, hacc[j], 0, 0, 0);                    \
-                        hacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah, hacc[j], 0, 0, 0);                    \
-                        hacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah, hacc[j], 0, 0, 0);                    \
+                    _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                    \
+                        const f16x8 wh = __builtin_bit_cast(f16x8, WCUR[n][0]), wl = __builtin_bit_cast(f16x8, WCUR[n][1]); \
+                        _Pragma("unroll") for (int j = 0; j < PNJ; ++j) {                                              \
+                            const f16x8 ah = __builtin_bit_cast(f16x8, xh[j]), al = __builtin_bit_cast(f16x8, xl[j]);  \
+                            pacc[n][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al, pacc[n][j], 0, 0, 0);          \
+                            pacc[n][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah, pacc[n][j], 0, 0, 0);          \
+                            pacc[n][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah, pacc[n][j], 0, 0, 0);          \
+                        }                                                                                              \
                     }                                                                                                  \
                     ++pst;                                                                                             \
                 }
@@ -873,32 +889,35 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
 #undef BSVD_PRE_TAP
                 __syncthreads();
             }
-            // the main conv's weight ring does NOT ride through this function (24 registers that the first conv's accumulators need):
-            // its slabs of the next two steps are requested here, in front of the mid epilogue that covers their latency
+        };
+        // pair PAIR of the first conv's output -> the two patch buffers (chunk 2 PAIR + h = buffer h): bias, activation, zero outside the
+        // image, split.  Both buffers are free (the barrier that ended the main conv's previous chunk).
+        [[maybe_unused]] auto pre_store = [&](auto pair_c, int bstep) {
+            constexpr int PAIR = decltype(pair_c)::value;
+            // the main conv's weight ring does not ride through the first conv (24 registers its accumulators need): the slabs of the
+            // next two steps are requested here, in front of the conversion that covers their latency
             load_b(bstep, b0);
             load_b(bstep + 1, b1);
-            // bias, activation, zero outside the image, split -> the two patch buffers (chunk 2 pair + h = buffer h)
-            const float *hb = p.pre_bias + pair * 32 + 8 * lh;
+            const float *hb = p.pre_bias + PAIR * 32 + 8 * lh;
             const f32x4 bia[2][2] = {{*reinterpret_cast<const f32x4 *>(hb), *reinterpret_cast<const f32x4 *>(hb + 4)},
                                      {*reinterpret_cast<const f32x4 *>(hb + 16), *reinterpret_cast<const f32x4 *>(hb + 20)}};
             const float vlo = p.pre_act >= BSVD_ACT_RELU ? 0.f : -65504.f, vhi = p.pre_act == BSVD_ACT_RELU6 ? 6.f : 65504.f;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                // (a wave's row tile beyond the patch -- wave 3's third -- is computed like the others on a clamped pixel and not stored:
-                //  wave-uniform branches around the MFMAs cost the whole function its register allocation, and the other three waves
-                //  have a third tile anyway)
+            for (int j = 0; j < PNJ; ++j) {
+                int a_s, d_p; bool px_in, px_st;
+                pre_geom(j, a_s, d_p, px_in, px_st);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     f16x8 hi, lo;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        float v = hacc[j][8 * h + k] + bia[h][k >> 2][k & 3];
-                        v = px_in[j] ? __builtin_amdgcn_fmed3f(v, vlo, vhi) : 0.f;
+                        float v = pacc[PAIR][j][8 * h + k] + bia[h][k >> 2][k & 3];
+                        v = px_in ? __builtin_amdgcn_fmed3f(v, vlo, vhi) : 0.f;
                         hi[k] = (_Float16)v;
                         lo[k] = lo_keep((_Float16)__builtin_fmaf((float)hi[k], -1.0f, v));
                     }
-                    float *dst = patch_buf + h * C::PATCH_FLOATS + d_p[j];
-                    if (px_st[j]) {
+                    float *dst = patch_buf + h * C::PATCH_FLOATS + d_p;
+                    if (px_st) {
                         *reinterpret_cast<f32x4 *>(dst) = __builtin_bit_cast(f32x4, hi);
                         *reinterpret_cast<f32x4 *>(dst + 2 * C::PLANE) = __builtin_bit_cast(f32x4, lo);
                     }
@@ -906,7 +925,7 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
             }
         };
         if constexpr (PREF) {
-            pre_request(0, true);          // chunk 0 of the first pair; everything else happens inside pre_pair
+            pre_request(0, true);          // chunk 0 of the first conv's input; everything else happens inside pre_all
         }
         else if constexpr (HEADF) {
             const float *xin = p.x + (int64_t)f * p.x_fs;
@@ -1023,12 +1042,15 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
                     fill_patch(cn, patch_buf + ((cb + 1) & 1) * C::PATCH_FLOATS);
                     __syncthreads();
                 }
-            } else
+            } else {
+            if constexpr (PREF) { pre_all(); zero_acc(); }       // the whole first conv, once per tile, in front of the main conv's K loop
             for (int cb = 0; cb < ncb; ++cb) {
                 if constexpr (FRONT) {
                     // both patch buffers are free here (the barrier that ended chunk cb - 1): fill them with chunks cb, cb + 1
                     if ((cb & 1) == 0) {
-                        if constexpr (HEADF) head_pair(cb >> 1); else pre_pair(cb >> 1, step);
+                        if constexpr (HEADF) head_pair(cb >> 1);
+                        else if (cb == 0) pre_store(std::integral_constant<int, 0>{}, step);
+                        else pre_store(std::integral_constant<int, 1>{}, step);
                         __syncthreads();
                     }
                 }
@@ -1090,12 +1112,16 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
                 if constexpr (!(BSVD_ABL & 1)) __syncthreads();
                 if constexpr (!C::DBUF) refill_single(cb, cn);
             }
-        } else
+            }
+        } else {
+        if constexpr (PREF) { pre_all(); zero_acc(); }
         for (int cb = 0; cb < ncb; ++cb) {
             if constexpr (FRONT) {
                 // both patch buffers are free here (the barrier that ended chunk cb - 1): fill them with chunks cb, cb + 1
                 if ((cb & 1) == 0) {
-                    if constexpr (HEADF) head_pair(cb >> 1); else pre_pair(cb >> 1, step);
+                    if constexpr (HEADF) head_pair(cb >> 1);
+                    else if (cb == 0) pre_store(std::integral_constant<int, 0>{}, step);
+                    else pre_store(std::integral_constant<int, 1>{}, step);
                     __syncthreads();
                 }
             }
@@ -1142,6 +1168,7 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
             }
             __syncthreads();   // one barrier per 16-channel chunk (9 taps, 288 MFMAs per wave)
             if constexpr (!C::DBUF) refill_single(cb, cn);
+        }
         }
     } else {
         // ============================================================================= GENERIC path

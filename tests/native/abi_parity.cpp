@@ -381,11 +381,46 @@ static void case_winograd() {
     if (bsvd_conv3x3(&a, nullptr) != -19 || !strstr(bsvd_last_error(), "stride")) { printf("w_wino_packed + stride 2 not refused\n"); ++failures; }
 }
 
+// case 9  OutputCvBlock's two convs (bsvd_arch.py:287-306) 64 -> 64 -> 64, ReLU6 / none, as ONE launch (ABI v10: BsvdConvArgs.pre_w_packed):
+//         against the two launches (bit for bit) and against the plain-C oracle's two convs (the tensor between them re-encoded as fp16 pairs)
+static void case_fused_pair() {
+    const int T = 2, C = 64, H = 21, W = 38;
+    auto x = randv((size_t)T * C * H * W, 1.5f), wa = randv((size_t)C * C * 9, 0.05f), ba = randv(C, 0.1f), wb = randv((size_t)C * C * 9, 0.05f), bb = randv(C, 0.1f);
+    auto xs = to_split16(to_nhwc(x, T, C, H, W, C));
+    x = to_nchw(from_split16(xs), T, C, H, W, C);
+    Packed pa = pack(wa, ba, C, C, C, C, 0, BSVD_F16X3), pb = pack(wb, bb, C, C, C, C, 0, BSVD_F16X3);
+    float *dx = dev(xs), *dmid = dev_zeros((size_t)T * H * W * C), *dy2 = dev_zeros((size_t)T * H * W * C), *dy1 = dev_zeros((size_t)T * H * W * C);
+    BsvdConvArgs a; memset(&a, 0, sizeof(a));
+    a.x = dx; a.x_frame_stride = (int64_t)H * W * C; a.y_frame_stride = (int64_t)H * W * C;
+    a.frames = T; a.H = H; a.W = W; a.Cin = C; a.Cout = C; a.stride = 1; a.epilogue = BSVD_EPI_PLAIN; a.dtype = BSVD_F16X3;
+    BsvdConvArgs a1 = a, a2 = a, af = a;
+    a1.w_packed = pa.w; a1.bias_packed = pa.b; a1.act = BSVD_ACT_RELU6; a1.y = dmid;
+    a2.x = dmid; a2.w_packed = pb.w; a2.bias_packed = pb.b; a2.act = BSVD_ACT_NONE; a2.y = dy2;
+    af.w_packed = pb.w; af.bias_packed = pb.b; af.act = BSVD_ACT_NONE; af.y = dy1;
+    af.pre_w_packed = pa.w; af.pre_bias = pa.b; af.pre_cin = C; af.pre_act = BSVD_ACT_RELU6;
+    char name[96]; ABI_OK(bsvd_conv3x3_variant(&af, name, sizeof(name)));
+    if (!strstr(name, "[fused pair]")) { printf("variant %s\n", name); ++failures; }
+    ABI_OK(bsvd_conv3x3(&a1, nullptr)); ABI_OK(bsvd_conv3x3(&a2, nullptr)); ABI_OK(bsvd_conv3x3(&af, nullptr)); HIP_OK(hipDeviceSynchronize());
+    auto y1 = host(dy1, (size_t)T * H * W * C), y2 = host(dy2, (size_t)T * H * W * C);
+    if (memcmp(y1.data(), y2.data(), y1.size() * 4) != 0) { printf("FAIL fused pair != the two launches bit for bit\n"); ++failures; }
+    auto got = to_nchw(from_split16(y1), T, C, H, W, C);
+    std::vector<float> mid((size_t)T * C * H * W), want((size_t)T * C * H * W);
+    const size_t fr = (size_t)C * H * W;
+    for (int t = 0; t < T; ++t)
+        if (oracle_conv3x3(x.data() + t * fr, nullptr, nullptr, 0, wa.data(), ba.data(), C, C, H, W, 1, 2, 0, nullptr, mid.data() + t * fr)) exit(4);
+    mid = to_nchw(from_split16(to_split16(to_nhwc(mid, T, C, H, W, C))), T, C, H, W, C);
+    for (int t = 0; t < T; ++t)
+        if (oracle_conv3x3(mid.data() + t * fr, nullptr, nullptr, 0, wb.data(), bb.data(), C, C, H, W, 1, 0, 0, nullptr, want.data() + t * fr)) exit(4);
+    report("OutputCvBlock pair 64->64->64 in one launch (pre_w_packed), split16 tensors", maxabs(got, want), 2e-4);
+    af.fold = 16;
+    if (bsvd_conv3x3(&af, nullptr) != -20 || !strstr(bsvd_last_error(), "fold")) { printf("pre_w_packed + fold not refused\n"); ++failures; }
+}
+
 int main() {
     if (bsvd_abi_version() != BSVD_ABI_VERSION || bsvd_conv_args_size() != (int)sizeof(BsvdConvArgs)) { printf("ABI mismatch\n"); return 1; }
     int n = 0; HIP_OK(hipGetDeviceCount(&n)); if (n < 1) { printf("no HIP device\n"); return 1; }
     HIP_OK(hipSetDevice(0));
-    case_tsm(); case_stride2(); case_pixel_shuffle(); case_split_chain(); case_fused_entry(); case_batch_and_graph(); case_stream_ring_graphs(); case_winograd();
+    case_tsm(); case_stride2(); case_pixel_shuffle(); case_split_chain(); case_fused_entry(); case_batch_and_graph(); case_stream_ring_graphs(); case_winograd(); case_fused_pair();
     printf(failures ? "abi_parity: %d FAILED\n" : "abi_parity: all cases ok\n", failures);
     return failures ? 1 : 0;
 }

@@ -38,7 +38,7 @@ def test_ring_graph_stream_equals_clip_bitwise(precision):
     assert st["graph_captures"] > 0 and st["graph_replays"] > st["graph_captures"]
 
 
-@pytest.mark.parametrize("wide_conv", ["direct", "wino2", "wino6", "wino26", "wino4"])
+@pytest.mark.parametrize("wide_conv", ["direct", "wino2", "wino6", "wino26"])      # (= engine.WIDE_CONV: the product forms)
 def test_every_form_of_the_wide_layers_streams_bit_identically_and_stays_in_the_error_class(wide_conv):
     """BSVD(wide_conv=...): the arithmetic form of the wide layers is a property of the model, so the reference's two call protocols
     (bsvd_arch.py:485-552 clip loop, :555-569 per-frame feed) agree bit for bit in every form -- also where a launch picks another tile
