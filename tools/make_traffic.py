@@ -15,13 +15,13 @@ import collections, csv, glob, json, os, re, sys
 
 def kernel_key(name):
     """rocprof kernel name -> the variant names bench.py uses (LaunchTimer.variant)."""
-    m = re.search(r"conv3x3_kernel<bsvd::ConvCfg<(\d+), (\d+), (\d+), (\d+), (\d+), \d+(?:, (?:true|false))?>, (true|false), (\d)(?:, (true|false))?(?:, (true|false))?>", name)
+    m = re.search(r"conv3x3_kernel<bsvd::ConvCfg<(\d+), (\d+), (\d+), (\d+), (\d+), \d+(?:, (?:true|false))?>, (true|false), (\d)(?:, (true|false))?(?:, (true|false))?(?:, (true|false))?>", name)
     if m:
-        mt, nt, wm, wn, st, fast, prec, mix, headf = m.groups()
+        mt, nt, wm, wn, st, fast, prec, mix, headf, pref = m.groups()
         planar = "[planar out]" if (mt, nt, wm, wn) == ("2", "1", "4", "1") and prec == "1" else ""     # the exit tile's only use
         return "conv3x3_kernel<%s,%s,%s,%s,%s>%s%s%s%s" % (mt, nt, wm, wn, st, "[f16x3]" if prec == "1" else "[f32]",
                                                           ("[fold8]" if mix == "true" else "") if fast == "true" else "[generic]",
-                                                          planar, "[fused entry]" if headf == "true" else "")
+                                                          planar, "[fused entry]" if headf == "true" else "") + ("[fused pair]" if pref == "true" else "")
     m = re.search(r"winox_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)>", name)
     if m:
         return "winox_kernel<F(%s,3),%sx%s>[f16x3]" % m.groups()[:3] + ("[8 rows]" if m.group(4) == "2" else "") + ("[persistent]" if m.group(5) == "true" else "")
