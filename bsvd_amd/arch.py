@@ -166,7 +166,7 @@ class _HipNet(nn.Module):
             # rate: take it whenever the network's channel layout admits it (the c64 / c32-sized networks do)
             precision = "f16x3" if self._split_ok else "fp32"
         elif precision == "f16x3" and not self._split_ok:
-            raise ValueError("precision='f16x3' needs temporal-fusion layers with fold % 16 == 0 or 64 channels (fold 8), "
+            raise ValueError("precision='f16x3' needs temporal-fusion layers with fold %% 16 == 0 or 64 channels (fold 8), "
                              "i.e. chns[1:] = (64|128k, 128k) like the c64 and c32 networks, and <= 4 input/output "
                              "channels; offending layers: %s" % (self._split_bad[:3],))
         self.precision_requested = requested

@@ -146,7 +146,9 @@ typedef struct BsvdConvArgs {
      * in ONE kernel: every tile computes the first conv on its own 18 x 18 patch (full K = 9 pre_cin on the matrix cores, the input
      * patch staged chunk by chunk through LDS) a pair of 16-channel chunks at a time, straight into the LDS patch of the second
      * conv; the Cin-channel tensor t never exists in HBM (1.33 GB written + read per 10-frame 540x960 clip at 64 channels).  The
-     * price is the halo: 324 patch pixels in 11 MFMA row tiles per 256 output pixels = 1.375x the first conv's MFMAs.  x is the first
+     * price is the halo: 324 patch pixels on 12 MFMA row-tile slots per 256 output pixels = 1.5x the first conv's MFMAs -- on the
+     * MI355X the pair is 11-13 % SLOWER than the two launches while moving half their HBM bytes: a choice for
+     * hosts short of bandwidth, not of matrix time.  x is the first
      * conv's NHWC input [frames][H][W][pre_cin] (x_frame_stride its frame stride); pre_w_packed = bsvd_pack_weights(dtype
      * BSVD_F16X3) of the first conv (pre_cin -> Cin), pre_bias its bias_packed [Cin].  Both convs: OutputCvBlock / InputCvBlock,
      * bsvd_arch.py:194-226, 287-306.  Needs pre_cin % 16 == 0, Cin % 32 == 0, Cout <= 64, stride 1, fold 0, no planar INPUT, no

@@ -19,11 +19,27 @@ def _slice_from_halo(halo, hw, n):
 
 
 class OracleExecutor:
-    def __init__(self, state, double=False):
+    def __init__(self, state, double=False, fuse_pairs=False):
         self.state = {k: torch.as_tensor(v, dtype=torch.float32) for k, v in state.items()}
         self.double = double
         self.launches = 0
         self.log = []
+        self.fuse_pairs = fuse_pairs      # claim engine.pair_fusable pairs as one launch (host-logic tests of the fused-pair plumbing)
+
+    def fuse_pair(self, S, na, nb):
+        from bsvd_amd.engine import pair_fusable
+        return bool(self.fuse_pairs and na in S and nb in S and pair_fusable(S[na], S[nb], "f16x3"))
+
+    def conv_pair_fused(self, spa, spb, x, extra=None, extra_pstride=0, extra_cstride=1, y_planar=None, out=None):
+        """two plain convs as ONE executor call (what BsvdConvArgs.pre_w_packed does on the device)"""
+        n0 = self.launches
+        y = self.conv(spb, self.conv(spa, x), extra=extra, extra_pstride=extra_pstride, extra_cstride=extra_cstride, y_planar=y_planar)
+        self.launches = n0 + 1
+        self.log[-2:] = [spa.key + "+" + spb.key]
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
 
     def to_nhwc(self, x_nchw, c_pad):
         T, C, H, W = x_nchw.shape
