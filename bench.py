@@ -66,17 +66,17 @@ def synth_clip(frames, seed, device, h=None, w=None):
     return lq.to(device), nm.to(device)
 
 
-def build_model(device, precision="fp32", blind=False, wide_conv="auto", fuse_pairs="auto"):
+def build_model(device, precision="fp32", blind=False, wide_conv="auto", fuse_pairs="auto", f32_handover="auto"):
     import bsvd_amd
     torch.manual_seed(1234)      # random-init weights of the bsvd_c64 architecture (no checkpoint in the tree)
     if blind:                    # options/test/0407...blind_c64.yml:97-121: interm_ch default 30, act default relu
         m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, shift_input=False, in_ch=4, out_ch=3, norm="none",
                           act="relu", interm_ch=30, blind=True, pretrain_ckpt=None, precision=precision, wide_conv=wide_conv,
-                          fuse_pairs=fuse_pairs)
+                          fuse_pairs=fuse_pairs, f32_handover=f32_handover)
     else:
         m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, shift_input=False, in_ch=4, out_ch=3, norm="none",
                           act="relu6", interm_ch=64, blind=False, pretrain_ckpt=None, precision=precision, wide_conv=wide_conv,
-                          fuse_pairs=fuse_pairs)
+                          fuse_pairs=fuse_pairs, f32_handover=f32_handover)
     return m.to(device).eval()
 
 
@@ -389,6 +389,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse-pairs", default="auto", choices=["auto", "on", "off"],
                     help="the 64-channel full-resolution conv pairs as one launch each (BSVD(fuse_pairs=...); auto = the product default)")
+    ap.add_argument("--f32-handover", default="auto", choices=["auto", "on", "off"],
+                    help="tensors only Winograd-form layers read as plain fp32 instead of fp16 pairs (BSVD(f32_handover=...); auto = on)")
     ap.add_argument("--wide-conv", default="auto", help="arithmetic form of the wide split-fp16 layers: auto (= wino2) | direct | wino2 | wino6 | "
                                                         "wino26 (bsvd_amd.engine.WIDE_CONV; the driver's line runs the default)")
     ap.add_argument("--no-power-probe", action="store_true", help="skip the 2.5 s rocm-smi power / clock sample after the timed region")
@@ -467,7 +469,8 @@ def main():
     def timed_run(precision, steps, warmup, prewarm_s=0.0, instrument=True, probe_s=0.0):
         """W untimed + K timed steps of the hot path at `precision`; returns (model, max-over-ranks seconds, per-kernel
         launch timings, last output)."""
-        model = build_model(device, precision, wl["blind"], args.wide_conv, {"auto": "auto", "on": True, "off": False}[args.fuse_pairs])
+        model = build_model(device, precision, wl["blind"], args.wide_conv, {"auto": "auto", "on": True, "off": False}[args.fuse_pairs],
+                            {"auto": "auto", "on": True, "off": False}[args.f32_handover])
         ex = model._executor(device)
         halo_fn = None
         if world > 1:

@@ -57,6 +57,7 @@ class BsvdConvArgs(ctypes.Structure):
         ("pre_w_packed", ctypes.c_void_p),
         ("pre_bias", ctypes.c_void_p),
         ("pre_cin", ctypes.c_int32), ("pre_act", ctypes.c_int32),
+        ("x_f32", ctypes.c_int32), ("y_f32", ctypes.c_int32),
     ]
 
 

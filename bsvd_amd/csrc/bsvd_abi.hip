@@ -362,6 +362,12 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
     p.y_planar_ch = a->y_planar_ch; p.y_clamp = a->y_clamp; p.y_lo = a->y_lo; p.y_hi = a->y_hi;
     p.head_w = nullptr; p.head_bias = nullptr; p.head_cin = 0;
     p.pre_w = nullptr; p.pre_bias = nullptr; p.pre_cin = 0; p.pre_act = 0;
+    p.x_f32 = a->x_f32 ? 1 : 0; p.y_f32 = a->y_f32 ? 1 : 0;
+    if (a->x_f32 && !(a->dtype == BSVD_F16X3 && a->w_wino_packed)) { set_error("bsvd_conv3x3: x_f32 is the Winograd form's input option (BSVD_F16X3 + w_wino_packed)"); return -21; }
+    if (a->y_f32 && (a->dtype != BSVD_F16X3 || a->y_planar_ch > 0 || a->epilogue == BSVD_EPI_RESID || a->pre_w_packed || a->head_w_packed ||
+                     (a->epilogue == BSVD_EPI_PS_ADD && !a->w_wino_packed))) {
+        set_error("bsvd_conv3x3: y_f32 needs BSVD_F16X3 and a PLAIN NHWC layer (direct or Winograd form) or a PS_ADD layer of the Winograd form"); return -21;
+    }
 #ifdef BSVD_ABLATE
     if (const char *e = getenv("BSVD_ABLATE")) p.ablate = atoi(e);
 #endif

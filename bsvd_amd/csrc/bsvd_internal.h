@@ -39,6 +39,8 @@ struct ConvParams {
     const void *pre_w;
     const float *pre_bias;
     int32_t pre_cin, pre_act;
+    // BsvdConvArgs.x_f32 / y_f32 (split mode): the input (Winograd form only) / the NHWC output holds plain fp32 channels instead of fp16 pairs
+    int32_t x_f32, y_f32;
     // Winograd form of the wide split-fp16 layers (BsvdConvArgs.w_wino_packed): w then points at the transformed pack
     int32_t fat_min_wgs;     // BsvdConvArgs.fat_min_wgs (0 = default): smallest grid that takes the 128-accumulator split tile
     int32_t wino_m;          // 0 = direct convolution; 2 | 4 | 6 = F(wino_m, 3) along x (conv3x3_winox.hip); 12 | 14 = the all-positions-per-wave kernel (conv3x3_wino.hip)

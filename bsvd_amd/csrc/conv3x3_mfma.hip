@@ -1328,8 +1328,10 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
         const int l_ch = n0 + wn * (C::NT * 32) + (PREC == 1 ? 8 * q : 8 * elh);
         const int64_t l_pix = (int64_t)l_oy * p.Wo + l_ox;
         const int64_t rowstride = (int64_t)p.Wo * p.Cout;
+        // (BsvdConvArgs.y_f32, PLAIN split layers: plain fp32 channels for a consumer that runs the Winograd form -- no split, no clamp)
+        const bool y_f32 = PREC == 1 && EPI == BSVD_EPI_PLAIN && p.y_f32 != 0;
         float *const l_base = p.y + (int64_t)f * p.y_fs + l_pix * p.Cout +
-                              (PREC == 1 ? (l_ch >> 4) * 16 + ((l_ch >> 3) & 1) * 4 : l_ch);
+                              ((PREC == 1 && !y_f32) ? (l_ch >> 4) * 16 + ((l_ch >> 3) & 1) * 4 : l_ch);
         // PixelShuffle items of the split mode, Cq % 32 == 0 (every c64 / c32-sized network): a 32-channel MFMA tile lies inside
         // ONE sub-pixel plane, so the sub-pixel, the channel base and the row are wave-uniform and an item's address is
         // (elane part, computed once) + (scalar part).  The generic form below divides by Cq and does 64-bit multiplies per
@@ -1503,7 +1505,11 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
                             if (j < p.resid_ch) v[j] = ecur[j >> 2][j & 3] - v[j];
                     }
                 }
-                if constexpr (PREC == 1) {
+                if (y_f32) {
+                    float *dst = t.dst;
+                    *reinterpret_cast<f32x4 *>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4 *>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else if constexpr (PREC == 1) {
                     float *dst = t.dst;
                     constexpr bool bounded = (ACT == BSVD_ACT_RELU6 && EPI == BSVD_EPI_PLAIN) || !BSVD_EPI_CLAMP;
                     f16x8 hi, lo;

@@ -217,7 +217,10 @@ __device__ __forceinline__ XChunkSrc x_chunk_src(const XTile t, int cbl)      //
 
 }  // namespace
 
-template <int M, int NH, int NTW, int MT, bool PERSIST>
+// XF (BsvdConvArgs.x_f32): the input tensor (and its halos) holds plain fp32 channels instead of fp16 pairs -- what a producer writes for a
+// tensor only Winograd layers read (BsvdConvArgs.y_f32).  The transform then starts from the value itself: no decode (4 of an item's
+// 8 v_fma_mix_f32 per channel pair), one 8-byte load per position instead of two 4-byte ones, and BT on channel PAIRS (v_pk_add_f32).
+template <int M, int NH, int NTW, int MT, bool PERSIST, bool XF = false>
 __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M, NH, NTW, MT, PERSIST>::NW / 4 * XCfg<M, NH, NTW, MT, PERSIST>::WGS)) void winox_kernel(const ConvParams p)
 {
     using C = XCfg<M, NH, NTW, MT, PERSIST>;
@@ -352,6 +355,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
 #define BSVD_WX_CH512 2    // channels per transform item of the 512-thread workgroups (2: 4-byte loads, two items per lane; 4: 8-byte loads, one)
 #endif
     constexpr int CH = C::NTHREADS == 512 ? (M == 2 ? BSVD_WX_CH512 : 2) : 4;
+    static_assert(!XF || CH == 2, "fp32 input: the 2-channel items of the 512-thread workgroups");
     constexpr int NDW = CH / 2;                                   // dwords per pixel and part
     struct Raw { unsigned h[A][NDW], l[A][NDW]; };
 #ifndef BSVD_WX_EMAP
@@ -374,6 +378,24 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
         int row, qb, g, sub;
         item_geom(E, row, qb, g, sub);
         const int gx0 = c.ox0 - 1 + M * g;
+        if constexpr (XF) {
+            // fp32 channels: the item's two channels 8 qb + sub / 2, + 1 are 8 contiguous bytes (8 adjacent lanes = one pixel's 64-byte chunk)
+            const unsigned base = active ? (unsigned)((c.oy0 - 1 + row) * p.W + gx0) * c.ps4 + (unsigned)(qb * 32 + 2 * sub) : BSVD_WX_OOB;
+            if (BSVD_WX_XIN && c.x_inside) {            // interior tile: scalar position offsets (see below)
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+                    const u32x2 v = buf_load2(c.rs, base, c.soff + (unsigned)i * c.ps4);
+                    r.h[i][0] = v[0]; r.l[i][0] = v[1];
+                }
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                const u32x2 v = buf_load2(c.rs, (unsigned)(gx0 + i) < (unsigned)p.W ? base + (unsigned)i * c.ps4 : BSVD_WX_OOB, c.soff);
+                r.h[i][0] = v[0]; r.l[i][0] = v[1];
+            }
+            return;
+        }
         const unsigned base = active ? (unsigned)((c.oy0 - 1 + row) * p.W + gx0) * c.ps4 + (unsigned)(qb * 16 + sub) : BSVD_WX_OOB;
         if (BSVD_WX_XIN && c.x_inside) {
             // every column of the patch is inside the image (all tiles but the first and last of a tile row): the A positions differ by a
@@ -411,6 +433,23 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
         int row, qb, g, sub;
         item_geom(E, row, qb, g, sub);
         unsigned char *dst = vbuf + qb * C::PLANE + (row * 8 + g) * 16 + sub;
+        if constexpr (XF) {
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            f32x2_t d[A], v[A];
+#pragma unroll
+            for (int i = 0; i < A; ++i) d[i] = f32x2_t{__builtin_bit_cast(float, r.h[i][0]), __builtin_bit_cast(float, r.l[i][0])};
+            F::input(d, v);                            // BT on the channel pair
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                unsigned hp, lp;
+                split_pair(v[i][0], v[i][1], hp, lp, mixk);
+                if (active) {
+                    *reinterpret_cast<unsigned *>(dst + i * 4 * C::PLANE) = hp;
+                    *reinterpret_cast<unsigned *>(dst + i * 4 * C::PLANE + 2 * C::PLANE) = lp;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int cp = 0; cp < NDW; ++cp) {            // a channel pair = one dword per position and part
             float v[2][A];
@@ -900,7 +939,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
                     if constexpr (EPI == BSVD_EPI_PS_ADD) {
                         const int sub = n8 / Cq, c8 = n8 - sub * Cq;
                         const int64_t upix = (int64_t)(2 * oy + (sub >> 1)) * (2 * p.Wo) + (2 * ox + (sub & 1));
-                        dst = p.y + (int64_t)f * p.y_fs + upix * Cq + coff16(c8);
+                        dst = p.y + (int64_t)f * p.y_fs + upix * Cq + (p.y_f32 ? c8 : coff16(c8));
                         if (has_skip && live) {
                             f16x8 eh, el;
                             if constexpr (SKIPPF) {
@@ -915,8 +954,12 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
                             for (int k = 0; k < 8; ++k) v[k] += (float)eh[k] + (float)el[k];
                         }
                     } else {
-                        dst = p.y + (int64_t)f * p.y_fs + ((int64_t)oy * p.Wo + ox) * p.Cout + coff16(n8);
+                        dst = p.y + (int64_t)f * p.y_fs + ((int64_t)oy * p.Wo + ox) * p.Cout + (p.y_f32 ? n8 : coff16(n8));
                     }
+                    if (live && p.y_f32) {       // BsvdConvArgs.y_f32: plain fp32 channels for a Winograd-only consumer (no split, no range clamp: its transform saturates)
+                        *reinterpret_cast<f32x4 *>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4 *>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    } else
                     if (live) {
                         constexpr bool bounded = (ACT == BSVD_ACT_RELU6 && EPI == BSVD_EPI_PLAIN) || !BSVD_EPI_CLAMP;
                         f16x8 hi, lo;
@@ -961,12 +1004,17 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
 #endif
 }
 
-template <int M, int NH, int NTW, int MT = 4, bool PERSIST = false>
+template <int M, int NH, int NTW, int MT = 4, bool PERSIST = false, bool XF = false>
 static int launch_winox_cfg(const ConvParams &pin, hipStream_t stream, char *name, int name_len, int max_wgs = BSVD_CUS)
 {
     using C = XCfg<M, NH, NTW, MT, PERSIST>;
+    if constexpr (!XF && !PERSIST && C::NTHREADS == 512 && (M == 2 || M == 6)) {      // the product configurations exist for both input formats
+        if (pin.x_f32) return launch_winox_cfg<M, NH, NTW, MT, PERSIST, true>(pin, stream, name, name_len, max_wgs);
+    } else if constexpr (!XF) {
+        if (pin.x_f32) { set_error("bsvd_conv3x3: x_f32 is not available for this Winograd variant"); return -19; }
+    }
     if (name) {
-        snprintf(name, name_len, "winox_kernel<F(%d,3),%dx%d>[f16x3]%s%s", M, NH, NTW, MT == 2 ? "[8 rows]" : "", PERSIST ? "[persistent]" : "");
+        snprintf(name, name_len, "winox_kernel<F(%d,3),%dx%d>[f16x3]%s%s%s", M, NH, NTW, MT == 2 ? "[8 rows]" : "", PERSIST ? "[persistent]" : "", XF ? "[f32 in]" : "");
         return 0;
     }
     ConvParams p = pin;
@@ -976,10 +1024,10 @@ static int launch_winox_cfg(const ConvParams &pin, hipStream_t stream, char *nam
     const int64_t nblk = (int64_t)p.frames * p.nty * p.ntx * p.nct;
     if (nblk <= 0 || nblk > 0x7fffffff) { set_error("bsvd_conv3x3: grid of %lld workgroups", (long long)nblk); return -1; }
     static std::atomic<int> granted[MAX_DEVICES];
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&winox_kernel<M, NH, NTW, MT, PERSIST>), C::LDS_BYTES, granted);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&winox_kernel<M, NH, NTW, MT, PERSIST, XF>), C::LDS_BYTES, granted);
     if (e != hipSuccess) return (int)e;
     const unsigned grid = PERSIST && nblk > max_wgs ? (unsigned)max_wgs : (unsigned)nblk;
-    hipLaunchKernelGGL((winox_kernel<M, NH, NTW, MT, PERSIST>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((winox_kernel<M, NH, NTW, MT, PERSIST, XF>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
     return (int)hipGetLastError();
 }
 

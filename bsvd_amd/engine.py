@@ -74,6 +74,14 @@ def wide_conv_known(name, lib=None):
     return False
 
 
+# Plain-fp32 hand-over (BsvdConvArgs.y_f32 / x_f32): a tensor whose only reader is a Winograd-form layer is stored as fp32 channels instead
+# of fp16 pairs -- same shape and bytes -- so that the reader's input transform starts from the value (no decode, half the load
+# instructions, BT on channel pairs).  producer -> its single consumer inside a DenBlock (bsvd_arch.py:374-396); x0 / x1 (skip tensors, read
+# by a direct-form layer too) and everything at full resolution stay pairs.
+F32_HANDOVER_DEFAULT = True
+_SOLE_CONSUMER = {"down0": "d0c1", "d0c1": "d0c2", "down1": "d1c1", "d1c1": "d1c2", "d1c2": "u2c1", "u2c1": "u2c2", "u2c2": "up2",
+                  "up2": "u1c1", "u1c1": "u1c2", "u1c2": "up1"}
+
 WINO_MIN_CIN = 128     # narrowest layer the Winograd form takes (engine.PackedNet(wino_min_cin=...))
 
 
@@ -90,7 +98,7 @@ class PackedNet:
     """Device-resident pre-packed weights of every layer (one-time transform of the state_dict,
     cf. BSVD.load, bsvd_arch.py:462-474): {spec.key: (w_packed, bias_packed)}."""
 
-    def __init__(self, net, state, device, precision="fp32", wide_conv="direct", wino_min_cin=None, fuse_pairs=False):
+    def __init__(self, net, state, device, precision="fp32", wide_conv="direct", wino_min_cin=None, fuse_pairs=False, f32_handover=None):
         lib = require_hip()
         if not wide_conv_known(wide_conv, lib):
             if wide_conv in MEASURE_WIDE_CONV:
@@ -159,6 +167,20 @@ class PackedNet:
                                                 sp0.cout_pad, hw.data_ptr(), hb.data_ptr(), _stream_ptr())
                 _lib.check(rc, "bsvd_pack_head_weights(%s)" % sp0.key)
                 self.head[sp3.key] = (hw, hb, sp0)
+            # plain-fp32 hand-over: producer -> consumer pairs whose consumer runs a product Winograd form and whose producer can store fp32
+            # (a Winograd-form layer, or a PLAIN direct-form split layer: the stride-2 convs).  Decided from the layer forms alone.
+            self.f32_out, self.f32_in = set(), set()
+            if (F32_HANDOVER_DEFAULT if f32_handover is None else f32_handover) and precision == "f16x3":
+                for blk in (getattr(net, "temp1", None), getattr(net, "temp2", None)):
+                    if blk is None:
+                        continue
+                    for pn, cn in _SOLE_CONSUMER.items():
+                        if pn in blk and cn in blk:
+                            pr, co = blk[pn], blk[cn]
+                            if self.wino_layer_abi.get(co.key) in (2, 6) and pr.cout_pad == co.cin_pad and \
+                                    (pr.key in self.wino or (pr.epilogue == EPI_PLAIN and pr.key not in edge)):
+                                self.f32_out.add(pr.key)
+                                self.f32_in.add(co.key)
             # fused 64-channel pairs (BsvdConvArgs.pre_w_packed), keyed by the SECOND conv: both layers keep their ordinary packs (the
             # first conv's is handed over as pre_w_packed / pre_bias), so a fused and an unfused launch read the same weights
             self.pairs = {}
@@ -211,6 +233,7 @@ class HipExecutor:
         # tuning override of the direct form's fat-tile threshold (BsvdConvArgs.fat_min_wgs; 0 = library default).  Read HERE, on the
         # host side of the ABI, once per executor -- the library itself reads no environment
         self.fat_min_wgs = int(os.environ.get("BSVD_FAT_MIN_WGS", "0") or 0)
+        self.force_x_f32 = self.force_y_f32 = None      # tests: override the pack's plain-fp32 hand-over decision for single layers
         self.record_variants = False     # profiling aid: ask the library which kernel instantiation each conv uses
         self.last_variant = None
 
@@ -396,6 +419,12 @@ class HipExecutor:
             if halo_next is not None:
                 a.halo_next, a.halo_next_pstride, a.halo_next_coff = halo_next.t.data_ptr(), halo_next.pstride, halo_next.coff
         a.bias_packed = bp.data_ptr()
+        yf = self.force_y_f32 if self.force_y_f32 is not None else sp.key in getattr(self.packed, "f32_out", ())
+        xf = self.force_x_f32 if self.force_x_f32 is not None else sp.key in getattr(self.packed, "f32_in", ())
+        if yf:
+            a.y_f32 = 1
+        if xf and wp is None:
+            a.x_f32 = 1
         if wp is not None:
             a.w_packed = wp.data_ptr()
         else:

@@ -157,6 +157,13 @@ typedef struct BsvdConvArgs {
     const void *pre_w_packed;
     const void *pre_bias;
     int32_t pre_cin, pre_act;
+    /* Plain-fp32 hand-over between split-mode layers (ABI v10, BSVD_F16X3 only).  A tensor that only Winograd-form layers read need
+     * not be carried as fp16 pairs: its producer stores the fp32 value itself (y_f32 != 0: PLAIN layers of the direct kernel, PLAIN and
+     * PS_ADD layers of the Winograd kernel; same [frames][H][W][C] shape, strides and bytes: 4 per value either way) and its consumer
+     * reads it as such (x_f32 != 0, with w_wino_packed only: x AND both halos hold fp32 channels).  The consumer's input transform then
+     * starts from the value -- no decode, one 8-byte load per position, the transform on channel pairs -- which takes about a fifth off
+     * the transform's instructions; values are exact fp32 instead of 22-bit pairs.  Anything else returns -21. */
+    int32_t x_f32, y_f32;
 } BsvdConvArgs;
 
 int bsvd_abi_version(void);

@@ -106,7 +106,7 @@ def test_whole_network_with_fused_pairs_is_bit_identical_in_every_schedule(blind
     dev = torch.device("cuda", 0)
     kw = dict(chns=[64, 128, 256], mid_ch=64, in_ch=4, out_ch=3, norm="none", pretrain_ckpt=None, precision="f16x3")
     kw.update(dict(act="relu", interm_ch=30, blind=True) if blind else dict(act="relu6", interm_ch=64))
-    st = seeded_state(bsvd_keys([64, 128, 256], 64, 3 if blind else 4, 3, 30 if blind else 64), 9)
+    st = seeded_state(bsvd_keys([64, 128, 256], 64, 4, 3, 30 if blind else 64, blind=blind), 9)
     models = {}
     for fp in (False, True):
         m = bsvd_amd.BSVD(fuse_pairs=fp, **kw)
