@@ -434,11 +434,25 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
         item_geom(E, row, qb, g, sub);
         unsigned char *dst = vbuf + qb * C::PLANE + (row * 8 + g) * 16 + sub;
         if constexpr (XF) {
+#ifndef BSVD_WX_XF_PK
+#define BSVD_WX_XF_PK 0     // fp32 input: 1 = BT on channel pairs (v_pk_add_f32 / v_pk_fma_f32): measured 5-7 % SLOWER per layer than channel by channel (r05e: packed fp32 beside MFMA waves), 0 = channel by channel
+#endif
+#if BSVD_WX_XF_PK
             typedef float f32x2_t __attribute__((ext_vector_type(2)));
             f32x2_t d[A], v[A];
 #pragma unroll
             for (int i = 0; i < A; ++i) d[i] = f32x2_t{__builtin_bit_cast(float, r.h[i][0]), __builtin_bit_cast(float, r.l[i][0])};
             F::input(d, v);                            // BT on the channel pair
+#else
+            float d0[A], d1[A], v0[A], v1[A];
+            float v[A][2];
+#pragma unroll
+            for (int i = 0; i < A; ++i) { d0[i] = __builtin_bit_cast(float, r.h[i][0]); d1[i] = __builtin_bit_cast(float, r.l[i][0]); }
+            F::input(d0, v0);
+            F::input(d1, v1);
+#pragma unroll
+            for (int i = 0; i < A; ++i) { v[i][0] = v0[i]; v[i][1] = v1[i]; }
+#endif
 #pragma unroll
             for (int i = 0; i < A; ++i) {
                 unsigned hp, lp;

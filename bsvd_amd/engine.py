@@ -177,7 +177,7 @@ class PackedNet:
                     for pn, cn in _SOLE_CONSUMER.items():
                         if pn in blk and cn in blk:
                             pr, co = blk[pn], blk[cn]
-                            if self.wino_layer_abi.get(co.key) in (2, 6) and pr.cout_pad == co.cin_pad and \
+                            if self.wino_layer_abi.get(co.key) in (2, 6) and pr.out_channels_pad == co.cin_pad and \
                                     (pr.key in self.wino or (pr.epilogue == EPI_PLAIN and pr.key not in edge)):
                                 self.f32_out.add(pr.key)
                                 self.f32_in.add(co.key)
