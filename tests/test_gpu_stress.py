@@ -48,9 +48,12 @@ def _families(m, ex):
     fams.append(("stride-2 tile", lambda: ex.conv(S["down0"], a0)))
     a2 = ex.conv(S["d0c1"], a1)                                   # temporal fusion 128 -> 128 (the wide form of the mode)
     fams.append(("wide temporal-fusion layer", lambda: ex.conv(S["d0c1"], a1)))
-    a3 = ex.conv(S["down1"], a2)
-    a4 = ex.conv(S["u2c1"], ex.conv(S["d1c1"], a3))
-    fams.append(("up-conv + PixelShuffle + skip", lambda: ex.conv(S["up2"], a4, extra=a2, extra_pstride=a2.shape[-1])))
+    # (every tensor goes where the network sends it: since round 5 a tensor only Winograd-form layers read is plain fp32, the skip
+    #  tensor x1 = downc0.c2's output stays an fp16-pair tensor)
+    x1 = ex.conv(S["d0c2"], a2)
+    a3 = ex.conv(S["down1"], x1)
+    a4 = ex.conv(S["u2c2"], ex.conv(S["u2c1"], ex.conv(S["d1c2"], ex.conv(S["d1c1"], a3))))
+    fams.append(("up-conv + PixelShuffle + skip", lambda: ex.conv(S["up2"], a4, extra=x1, extra_pstride=x1.shape[-1])))
     S2 = net.temp2                                                # second DenBlock: NHWC 64-channel input, planar exit
     o0 = ex.conv(S2["out0"], a0)
     fams.append(("64-channel tile (out0)", lambda: ex.conv(S2["out0"], a0)))

@@ -13,7 +13,10 @@ ap.add_argument("--frames", default="10,85")
 ap.add_argument("--precision", default="f16x3")
 ap.add_argument("--reps", type=int, default=4)
 ap.add_argument("--json", default=None)
+ap.add_argument("--f32-handover", default="auto", choices=["auto", "on", "off"])
+ap.add_argument("--fuse-pairs", default="auto", choices=["auto", "on", "off"])
 a = ap.parse_args()
+_TRI = {"auto": "auto", "on": True, "off": False}
 H, W = map(int, a.size.split("x"))
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
@@ -22,7 +25,7 @@ torch.manual_seed(0)
 def model(**kw):
     torch.manual_seed(1234)
     return bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, norm="none", act="relu6", interm_ch=64, pretrain_ckpt=None,
-                         precision=a.precision, **kw).to(dev).eval()
+                         precision=a.precision, f32_handover=_TRI[a.f32_handover], fuse_pairs=_TRI[a.fuse_pairs], **kw).to(dev).eval()
 
 
 def per_frame(m, x):
