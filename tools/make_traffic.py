@@ -22,9 +22,10 @@ def kernel_key(name):
         return "conv3x3_kernel<%s,%s,%s,%s,%s>%s%s%s%s" % (mt, nt, wm, wn, st, "[f16x3]" if prec == "1" else "[f32]",
                                                           ("[fold8]" if mix == "true" else "") if fast == "true" else "[generic]",
                                                           planar, "[fused entry]" if headf == "true" else "") + ("[fused pair]" if pref == "true" else "")
-    m = re.search(r"winox_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)>", name)
+    m = re.search(r"winox_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)(?:, (true|false))?>", name)
     if m:
-        return "winox_kernel<F(%s,3),%sx%s>[f16x3]" % m.groups()[:3] + ("[8 rows]" if m.group(4) == "2" else "") + ("[persistent]" if m.group(5) == "true" else "")
+        return "winox_kernel<F(%s,3),%sx%s>[f16x3]" % m.groups()[:3] + ("[8 rows]" if m.group(4) == "2" else "") + ("[persistent]" if m.group(5) == "true" else "") + \
+               ("[f32 in]" if m.group(6) == "true" else "")
     m = re.search(r"wino_kernel<(\d+)>", name)
     if m:
         return "wino_kernel<F(%s,3)>[f16x3]" % m.group(1)
