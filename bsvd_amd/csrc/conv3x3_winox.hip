@@ -553,10 +553,37 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
     };
     int rot_base = 0;          // chunks of the workgroup's earlier tiles: the rotation runs on across tiles (a chunk is requested under one tile's
                                // numbering and finished under the next one's)
+#ifndef BSVD_WX_ROTA
+#define BSVD_WX_ROTA 0     // how a chunk's transform items are dealt to the 8 waves of the F(2,3) / F(6,3) workgroups (bit-identical results):
+                           //   0  evenly: two 64-item blocks per wave + the two left-over blocks rotating over all eight waves
+                           //   1  the left-over blocks rotate over the four MFMA-FIRST waves only (waves 0-3)
+                           //   2  three blocks per MFMA-first wave, one per transform-first wave + the two left-over blocks rotating over those
+                           // Why: the waves that transform FIRST are the chunk's critical path (timeline r04b: transform 1881 + MFMA steps 4222 cycles
+                           // against 3393 + 1698 for the MFMA-first waves, which then wait 1300 cycles at the chunk barrier)
+#endif
     auto rot_slot = [&](int cc) __attribute__((always_inline)) {                // 0 / 1: this wave takes left-over block 0 / 1 of chunk cc, -1: none
         if constexpr (NROT == 0) return -1;
+        if constexpr (BSVD_WX_ROTA == 1 && C::NW == 8) {
+            if (wid >= 4) return -1;
+            const int d4 = (wid - (cc + rot_base) % 4 + 4) % 4;
+            return d4 < NROT ? d4 : -1;
+        }
         const int d = (wid - (cc + rot_base) % C::NW + C::NW) % C::NW;
         return d < NROT ? d : -1;
+    };
+    // ROTA == 2: block map.  NB = NITEMS / 64 blocks of 64 items (18 on the full tile, 10 on the 8-row tile); MFMA-first wave w (0..3) takes
+    // blocks w, 4 + w, (8 + w); transform-first wave w (4..7) takes block 4 KA + w - 4 (full tile only) and, when the rotation picks it, one of
+    // the last two.  Slot k of a wave's raw register sets: k < KA for the first group; k = 0 fixed (full tile) and the next slot rotating for the second.
+    constexpr bool ROTA2 = BSVD_WX_ROTA == 2 && C::NTHREADS == 512 && CH == 2 && !PERSIST && !DEADROWS && NROT == 2;
+    constexpr int KA = C::MT == 4 ? 3 : 2, KBF = C::MT == 4 ? 1 : 0;
+    auto rota_block = [&](int cc, int k) __attribute__((always_inline)) {       // block of slot k for this wave in chunk cc, -1: none (wave uniform)
+        if (wid < 4) return k < KA ? k * 4 + wid : -1;
+        if (k < KBF) return 4 * KA + (wid - 4);
+        if (k == KBF) {
+            const int d4 = ((wid - 4) - (cc + rot_base) % 4 + 4) % 4;
+            return d4 < 2 ? 4 * KA + 4 * KBF + d4 : -1;
+        }
+        return -1;
     };
     // PP raw register sets: chunk cc's items live in set cc % PP.  PP = 2 where the registers are there (F(2,3)): an item is then
     // requested TWO chunks before it is finished
@@ -567,13 +594,23 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
 #define BSVD_WX_PP 2       // raw register sets of F(2,3)'s 512-thread workgroups
 #endif
     constexpr int PP = (M == 2 && C::NTHREADS == 512 && BSVD_WX_ILV != 2) ? (PERSIST ? BSVD_WX_PP_PERSIST : BSVD_WX_PP) : 1;
-    Raw raw[PP][NMAIN], raw_rot[PP];
+    static_assert(!ROTA2 || (KA <= 3 && NITEMS == (4 * KA + 4 * KBF + 2) * 64), "ROTA 2: block count");
+    constexpr int NSLOTS = ROTA2 ? KA : NMAIN;
+    Raw raw[PP][NSLOTS], raw_rot[PP];
     using PAll = std::integral_constant<int, 3>;     // part_: 1 the lanes' main items, 2 the rotating left-over block, 3 both
     auto chunk_load = [&](int cc, int SET, auto part_, int tl) __attribute__((always_inline)) {
         // beyond T's last chunk: the first chunks of the workgroup's next tile (or of a dead tile: zeros)
         XChunkSrc c;
         if (cc >= T.S.ncb) c = x_chunk_src(next_tile(), cc - T.S.ncb);
         else c = x_chunk_src(T, cc);
+        if constexpr (ROTA2) {
+#pragma unroll
+            for (int k = 0; k < NSLOTS; ++k) {
+                const int blk = rota_block(cc, k);
+                if (blk >= 0) item_load(c, blk * 64 + tl, true, raw[SET][k]);
+            }
+            return;
+        }
         if constexpr (decltype(part_)::value & 1) {
 #pragma unroll
         for (int k = 0; k < NMAIN; ++k) if (!sweep_dead(k)) item_load(c, main_E(k, tl), main_active(k, tl), raw[SET][k]);
@@ -589,6 +626,14 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
         }
     };
     auto chunk_finish = [&](int cc, unsigned char *vbuf, int SET, auto part_, int tl) __attribute__((always_inline)) {
+        if constexpr (ROTA2) {
+#pragma unroll
+            for (int k = 0; k < NSLOTS; ++k) {
+                const int blk = rota_block(cc, k);
+                if (blk >= 0) item_finish(vbuf, blk * 64 + tl, true, raw[SET][k]);
+            }
+            return;
+        }
         if constexpr (decltype(part_)::value & 1) {
 #pragma unroll
         for (int k = 0; k < NMAIN; ++k) if (!sweep_dead(k)) item_finish(vbuf, main_E(k, tl), main_active(k, tl), raw[SET][k]);
