@@ -148,3 +148,43 @@ def test_random_networks_with_the_wide_layers_forced_onto_the_128_accumulator_ti
                        text=True, timeout=900)
     print(r.stdout[-3000:])
     assert r.returncode == 0 and "FUZZ NETS OK 6" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_fused_pairs_equal_their_two_launches(seed):
+    """The fused conv pair (BsvdConvArgs.pre_w_packed, bsvd_arch.py:194-226, 287-306) on random channel counts (16 .. 64 in, 32 / 64 mid, 16 .. 64 out),
+    ragged sizes, 1 to 3 frames, the three activations, PLAIN / RESID epilogues: bit-equal to the two launches."""
+    import torch
+    import test_gpu_pair as P
+    from test_gpu_f16x3 import to_split
+    rs = np.random.RandomState(9000 + seed)
+    ca, cm, cb = int(rs.choice([16, 32, 48, 64])), int(rs.choice([32, 64])), int(rs.choice([16, 32, 48, 64]))
+    act_a = str(rs.choice(["relu6", "relu", "none"]))
+    epi = int(rs.choice([0, 0, 2]))
+    act_b = "none" if epi == 2 else str(rs.choice(["relu6", "relu", "none"]))
+    T, H, W = int(rs.randint(1, 4)), int(rs.randint(1, 40)), int(rs.randint(1, 50))
+    a, b, st, fused, plain = P._setup(ca, cm, cb, act_a, act_b, epi, seed=seed)
+    xs = to_split(torch.from_numpy((rs.rand(T, H, W, ca) * 4 - 1).astype(np.float32))).cuda()
+    kw = {}
+    if epi == 2:
+        kw = dict(extra=torch.from_numpy(rs.rand(T, 4, H, W).astype(np.float32)).cuda(), extra_pstride=1, extra_cstride=H * W)
+    print("case", ca, cm, cb, act_a, act_b, epi, T, H, W)
+    assert torch.equal(fused.conv_pair_fused(a, b, xs, **kw), plain.conv(b, plain.conv(a, xs), **kw))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_wide_layers_with_fp32_handover(seed):
+    """The Winograd kernels reading / writing plain fp32 (BsvdConvArgs.x_f32 / y_f32) on the random eligible layers of
+    test_random_wide_layer_winograd_forms' generator."""
+    import test_gpu_f32_handover as F
+    import test_gpu_wino as WN
+    rs = np.random.RandomState(7000 + seed)
+    form = WN.PRODUCT_FORMS[seed % 2]
+    epi = int(rs.choice([0, 0, 1]))
+    tsm = bool(epi == 0 and rs.rand() < 0.6)
+    cin = int(rs.choice([128, 256]))
+    cout = cin if tsm else int(rs.choice([128, 256, 512] if epi == 1 else [64, 128, 256]))
+    act = str(rs.choice(["relu6", "relu", "none"])) if epi == 0 else "none"
+    T, H, W = int(rs.randint(1, 4)), int(rs.randint(1, 21)), int(rs.randint(1, 49))
+    print("case", form, cin, cout, tsm, act, epi, T, H, W)
+    F.test_wino_layer_with_fp32_input_and_output_vs_oracle(form, cin, cout, tsm, act, epi, T, H, W)
