@@ -220,8 +220,11 @@ __device__ __forceinline__ XChunkSrc x_chunk_src(const XTile t, int cbl)      //
 // XF (BsvdConvArgs.x_f32): the input tensor (and its halos) holds plain fp32 channels instead of fp16 pairs -- what a producer writes for a
 // tensor only Winograd layers read (BsvdConvArgs.y_f32).  The transform then starts from the value itself: no decode (4 of an item's
 // 8 v_fma_mix_f32 per channel pair), one 8-byte load per position instead of two 4-byte ones, and BT on channel PAIRS (v_pk_add_f32).
-template <int M, int NH, int NTW, int MT, bool PERSIST, bool XF = false>
-__global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M, NH, NTW, MT, PERSIST>::NW / 4 * XCfg<M, NH, NTW, MT, PERSIST>::WGS)) void winox_kernel(const ConvParams p)
+// The whole workgroup body as a device function, so that one launch can run two tile heights: GTR = rows of the tile GRID (p.nty was
+// computed for it); the body computes C::TR <= GTR of them from the tile's first row (winox_kernel_tail: the last row band of a
+// 135- or 120-row layer has <= 8 live rows and runs the 8-row body on the 16-row grid).
+template <int M, int NH, int NTW, int MT, bool PERSIST, bool XF, int GTR>
+__device__ __forceinline__ void winox_tile(const ConvParams &p)
 {
     using C = XCfg<M, NH, NTW, MT, PERSIST>;
     using F = WinoForm<M>;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
         const int tx = lid % p.ntx; lid /= p.ntx;
         const int ty = lid % p.nty;
         const int f = lid / p.nty;
-        t.f = f; t.oy0 = ty * C::TR; t.ox0 = tx * C::TWPX; t.n0 = ct * C::BN;
+        t.f = f; t.oy0 = ty * GTR; t.ox0 = tx * C::TWPX; t.n0 = ct * C::BN;
         t.x_inside = t.ox0 >= 1 && t.ox0 + C::TWPX + 1 <= p.W;
         // temporal sources of this frame
         const float *cur = p.x + (int64_t)f * p.x_fs;
@@ -1063,6 +1066,30 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
 #endif
 }
 
+template <int M, int NH, int NTW, int MT, bool PERSIST, bool XF = false>
+__global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M, NH, NTW, MT, PERSIST>::NW / 4 * XCfg<M, NH, NTW, MT, PERSIST>::WGS)) void winox_kernel(const ConvParams p)
+{
+    winox_tile<M, NH, NTW, MT, PERSIST, XF, XCfg<M, NH, NTW, MT, PERSIST>::TR>(p);
+}
+
+// 16-row tile grid whose LAST row band has <= 8 live rows (Ho mod 16 in 1..8: the 135-row layers of a 540 x 960 frame, the 120-row ones of
+// 480 x 856): those workgroups run the 8-row body -- the same instruction sequence per output (bit-identical, like the 8-row tile of
+// small grids), 0.57 of a full tile's time for tiles that are <= half alive.  A wave-uniform branch at the very top, two complete
+// bodies: nothing inside the K loops knows about it (the in-loop form, BSVD_WX_DEADROWS, cost every tile its MFMA schedule).
+template <int M, int NH, int NTW, bool XF>
+__global__ __launch_bounds__((XCfg<M, NH, NTW, 4, false>::NTHREADS), (XCfg<M, NH, NTW, 4, false>::NW / 4)) void winox_kernel_tail(const ConvParams p)
+{
+    // this workgroup's tile row, decoded like winox_tile does (XCD-contiguous tile ranges, optional reverse walk)
+    const int ntiles = p.frames * p.nty * p.ntx * p.nct;
+    const int bid = blockIdx.x, xcd = bid & 7;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    if (p.flip) lid = ntiles - 1 - lid;
+    const int ty = (lid / (p.nct * p.ntx)) % p.nty;
+    if (p.nty >= 2 && p.Ho - ty * 16 <= 8) winox_tile<M, NH, NTW, 2, false, XF, 16>(p);
+    else winox_tile<M, NH, NTW, 4, false, XF, 16>(p);
+}
+
 template <int M, int NH, int NTW, int MT = 4, bool PERSIST = false, bool XF = false>
 static int launch_winox_cfg(const ConvParams &pin, hipStream_t stream, char *name, int name_len, int max_wgs = BSVD_CUS)
 {
@@ -1082,12 +1109,25 @@ static int launch_winox_cfg(const ConvParams &pin, hipStream_t stream, char *nam
     p.nct = (p.Cout + C::BN - 1) / C::BN;
     const int64_t nblk = (int64_t)p.frames * p.nty * p.ntx * p.nct;
     if (nblk <= 0 || nblk > 0x7fffffff) { set_error("bsvd_conv3x3: grid of %lld workgroups", (long long)nblk); return -1; }
-    static std::atomic<int> granted[MAX_DEVICES];
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&winox_kernel<M, NH, NTW, MT, PERSIST, XF>), C::LDS_BYTES, granted);
-    if (e != hipSuccess) return (int)e;
-    const unsigned grid = PERSIST && nblk > max_wgs ? (unsigned)max_wgs : (unsigned)nblk;
-    hipLaunchKernelGGL((winox_kernel<M, NH, NTW, MT, PERSIST, XF>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
-    return (int)hipGetLastError();
+#ifndef BSVD_WX_TAIL
+#define BSVD_WX_TAIL 1     // 16-row tile grids whose last row band has <= 8 live rows run that band on the 8-row body (winox_kernel_tail)
+#endif
+    // the product's 16-row tile launches are ALL this kernel (one symbol per form in a profile): a grid without such a band never takes
+    // the branch
+    if constexpr (BSVD_WX_TAIL && MT == 4 && !PERSIST && C::NTHREADS == 512 && (M == 2 || M == 6)) {
+        static std::atomic<int> granted_t[MAX_DEVICES];
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&winox_kernel_tail<M, NH, NTW, XF>), C::LDS_BYTES, granted_t);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((winox_kernel_tail<M, NH, NTW, XF>), dim3((unsigned)nblk), dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
+        return (int)hipGetLastError();
+    } else {
+        static std::atomic<int> granted[MAX_DEVICES];
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&winox_kernel<M, NH, NTW, MT, PERSIST, XF>), C::LDS_BYTES, granted);
+        if (e != hipSuccess) return (int)e;
+        const unsigned grid = PERSIST && nblk > max_wgs ? (unsigned)max_wgs : (unsigned)nblk;
+        hipLaunchKernelGGL((winox_kernel<M, NH, NTW, MT, PERSIST, XF>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
+        return (int)hipGetLastError();
+    }
 }
 
 // Which wino_m codes this build runs.  Product: 2 / 6 (F(2,3) / F(6,3), each picking the half-height tile for grids that do not fill the

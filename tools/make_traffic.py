@@ -26,6 +26,9 @@ def kernel_key(name):
     if m:
         return "winox_kernel<F(%s,3),%sx%s>[f16x3]" % m.groups()[:3] + ("[8 rows]" if m.group(4) == "2" else "") + ("[persistent]" if m.group(5) == "true" else "") + \
                ("[f32 in]" if m.group(6) == "true" else "")
+    m = re.search(r"winox_kernel_tail<(\d+), (\d+), (\d+), (true|false)>", name)      # the product's 16-row tile launches (an 8-row body for a short last band)
+    if m:
+        return "winox_kernel<F(%s,3),%sx%s>[f16x3]" % m.groups()[:3] + ("[f32 in]" if m.group(4) == "true" else "")
     m = re.search(r"wino_kernel<(\d+)>", name)
     if m:
         return "wino_kernel<F(%s,3)>[f16x3]" % m.group(1)
