@@ -81,7 +81,20 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-template <int M_, int NH_, int NTW_, int MT_ = 4, bool PERSIST_ = false>
+// The tile grid of a launch, shared by the launcher and the kernels.  fold: the grid's last row band (<= 8 live rows of a 16-row tile grid) is walked by
+// workgroups that each take TWO horizontally adjacent tiles of it as the two halves of one 16-row tile (XCfg::FOLD): tiles per frame =
+// nreg regular ones (nct * ntx * (nty - 1), channel tile fastest) + nct * ceil(ntx / 2) folded ones.
+struct WxGrid { int per_frame, nreg; bool fold; };
+__host__ __device__ __forceinline__ WxGrid wx_grid(int nty, int ntx, int nct, int Ho, bool may_fold)
+{
+    WxGrid g;
+    g.fold = may_fold && nty >= 2 && Ho - (nty - 1) * 16 <= 8;
+    g.nreg = g.fold ? nct * ntx * (nty - 1) : nct * ntx * nty;
+    g.per_frame = g.fold ? g.nreg + nct * ((ntx + 1) >> 1) : g.nreg;
+    return g;
+}
+
+template <int M_, int NH_, int NTW_, int MT_ = 4, bool PERSIST_ = false, bool FOLD_ = false>
 struct XCfg {
     static constexpr bool PERSIST = PERSIST_;     // one workgroup per CU walks a list of tiles; the transform pipeline runs across tile boundaries
     static constexpr int M = M_, A = M + 2, NH = NH_, NTW = NTW_;
@@ -89,7 +102,14 @@ struct XCfg {
     static constexpr int MT = MT_;                // MFMA tiles of the pixel tile: 8 groups x 4 rows each.  MT = 2: the half-height tile small grids
                                                   // take (launch_winox) -- same arithmetic per output, twice the workgroups
     static constexpr int TR = 4 * MT, TWPX = 8 * M;   // pixel tile: 16 (8) rows x 8 M columns
-    static constexpr int PR = TR + 2;             // patch rows
+    // FOLD: the 16 tile rows are two 8-row halves side by side in the image -- rows 0-7 at (oy0, ox0), rows 8-15 at (oy0, ox0 + TWPX): each half
+    // has its own 10 patch rows (patch rows 0-9 / 10-19), MFMA tiles 2, 3 read theirs two rows further down, the epilogue's second round
+    // stores 8 rows up and TWPX columns to the right.  Everything else -- the item sweeps, the MFMA steps, the exchange -- is the 16-row tile's.
+    static constexpr bool FOLD = FOLD_;
+    static_assert(!FOLD || (MT_ == 4 && !PERSIST_), "folded tile: the full-height tile, one tile per workgroup");
+    static constexpr int PR = TR + 2 + (FOLD ? 2 : 0);     // patch rows
+    static constexpr int PRH = TR / 2 + 2;                 // (FOLD) patch rows of a half
+    static constexpr int frag_row(int mt, int ky) { return 4 * mt + ky + (FOLD && mt >= 2 ? 2 : 0); }      // patch row of MFMA tile mt's first row, kernel row ky
     static constexpr int NSLOT = PR * 8;
 #ifndef BSVD_WX_PLANE_PAD
 #define BSVD_WX_PLANE_PAD 0     // bytes added to a plane.  NSLOT * 16 is a multiple of 256 B (all 64 banks), so the two quarters an item wave stores at
@@ -223,10 +243,11 @@ __device__ __forceinline__ XChunkSrc x_chunk_src(const XTile t, int cbl)      //
 // The whole workgroup body as a device function, so that one launch can run two tile heights: GTR = rows of the tile GRID (p.nty was
 // computed for it); the body computes C::TR <= GTR of them from the tile's first row (winox_kernel_tail: the last row band of a
 // 135- or 120-row layer has <= 8 live rows and runs the 8-row body on the 16-row grid).
-template <int M, int NH, int NTW, int MT, bool PERSIST, bool XF, int GTR>
+// FG: 0 the plain grid; 1 / 2 the launch's grid may be a folded one (wx_grid): 1 = this workgroup runs a regular tile of it, 2 = a folded tile.
+template <int M, int NH, int NTW, int MT, bool PERSIST, bool XF, int GTR, int FG = 0>
 __device__ __forceinline__ void winox_tile(const ConvParams &p)
 {
-    using C = XCfg<M, NH, NTW, MT, PERSIST>;
+    using C = XCfg<M, NH, NTW, MT, PERSIST, FG == 2>;
     using F = WinoForm<M>;
     constexpr int A = C::A;
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
@@ -243,7 +264,8 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
     // ---- workgroup -> tiles (frame, tile y, tile x, channel tile), XCD-aware like the direct kernel: block b runs on XCD b % 8 and
     //      every XCD owns one contiguous range of the tile list (neighbouring tiles share halo rows and weights in that XCD's L2).
     //      One tile per workgroup -- or, PERSIST, the workgroups of an XCD deal its range among themselves round robin.
-    const int ntiles = p.frames * p.nty * p.ntx * p.nct;
+    const WxGrid G = wx_grid(p.nty, p.ntx, p.nct, p.Ho, FG != 0);
+    const int ntiles = p.frames * G.per_frame;
     const int bid = blockIdx.x, xcd = bid & 7;
     const int q8 = ntiles >> 3, r8 = ntiles & 7;
     const int xcd_first = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, xcd_count = q8 + (xcd < r8 ? 1 : 0);
@@ -254,12 +276,12 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
         const bool live = j < xcd_count;
         int lid = xcd_first + (live ? j : 0);
         if (p.flip) lid = ntiles - 1 - lid;
-        const int ct = lid % p.nct; lid /= p.nct;
-        const int tx = lid % p.ntx; lid /= p.ntx;
-        const int ty = lid % p.nty;
-        const int f = lid / p.nty;
+        const int f = lid / G.per_frame;
+        int r = lid - f * G.per_frame, ct, tx, ty;
+        if (FG != 0 && G.fold && r >= G.nreg) { r -= G.nreg; ct = r % p.nct; tx = 2 * (r / p.nct); ty = p.nty - 1; }
+        else { ct = r % p.nct; r /= p.nct; tx = r % p.ntx; ty = r / p.ntx; }
         t.f = f; t.oy0 = ty * GTR; t.ox0 = tx * C::TWPX; t.n0 = ct * C::BN;
-        t.x_inside = t.ox0 >= 1 && t.ox0 + C::TWPX + 1 <= p.W;
+        t.x_inside = t.ox0 >= 1 && t.ox0 + (C::FOLD ? 2 : 1) * C::TWPX + 1 <= p.W;
         // temporal sources of this frame
         const float *cur = p.x + (int64_t)f * p.x_fs;
         const float *prv, *nxt;
@@ -380,7 +402,12 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
     auto item_load = [&](const XChunkSrc &c, int E, bool active, Raw &r) __attribute__((always_inline)) {
         int row, qb, g, sub;
         item_geom(E, row, qb, g, sub);
-        const int gx0 = c.ox0 - 1 + M * g;
+        int gx0 = c.ox0 - 1 + M * g;
+        if constexpr (C::FOLD) {          // patch rows 10 .. 19: the second half's, TWPX columns to the right
+            const bool up = row >= C::PRH;
+            row = up ? row - C::PRH : row;
+            gx0 = up ? gx0 + C::TWPX : gx0;
+        }
         if constexpr (XF) {
             // fp32 channels: the item's two channels 8 qb + sub / 2, + 1 are 8 contiguous bytes (8 adjacent lanes = one pixel's 64-byte chunk)
             const unsigned base = active ? (unsigned)((c.oy0 - 1 + row) * p.W + gx0) * c.ps4 + (unsigned)(qb * 32 + 2 * sub) : BSVD_WX_OOB;
@@ -531,7 +558,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
                                // 256 -> 512 =, and 128 -> 128 at 270 rows (no such tile) +1.7 % -- the six wave-uniform branches split the MFMA steps'
                                // scheduling regions for every tile.  Net zero on the clip: off
 #endif
-    constexpr bool DEADROWS = BSVD_WX_DEADROWS && M == 2 && C::MT == 4 && !PERSIST && BSVD_WX_ILV == 0;    // (F(6,3): 25 spills with it)
+    constexpr bool DEADROWS = BSVD_WX_DEADROWS && M == 2 && C::MT == 4 && !PERSIST && !C::FOLD && BSVD_WX_ILV == 0;    // (F(6,3): 25 spills with it)
     bool half_live = false;        // wave uniform, set per tile
     // first patch row of main item sweep k of this wave (a wave's 64 items of a sweep are one row, or two with 4-channel items)
     auto sweep_dead = [&](int k) __attribute__((always_inline)) { return half_live && ((k * C::NTHREADS + wid * 64) >> (CH == 4 ? 5 : 6)) > 9; };
@@ -699,7 +726,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
                         constexpr int KY1 = (S_ + 1) / NMT, mt1 = (S_ + 1) % NMT;
 #pragma unroll
                         for (int pt = 0; pt < 2; ++pt)
-                            afr[(S_ + 1) & 1][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE + (4 * mt1 + KY1) * 128);
+                            afr[(S_ + 1) & 1][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE + C::frag_row(mt1, KY1) * 128);
                     }
                     const f32x4 (&a)[2] = afr[S_ & 1];
                     __builtin_amdgcn_sched_barrier(0);
@@ -785,7 +812,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
                         constexpr int KY1 = (S_ + 1) / C::MT, mt1 = (S_ + 1) % C::MT;
 #pragma unroll
                         for (int pt = 0; pt < 2; ++pt)
-                            afr[(S_ + 1) & 1][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE + (4 * mt1 + KY1) * 128);
+                            afr[(S_ + 1) & 1][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE + C::frag_row(mt1, KY1) * 128);
                     }
                     const f32x4 (&a)[2] = afr[S_ & 1];
 #pragma unroll
@@ -925,6 +952,9 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
             // PixelShuffle + skip: the skip values of this round's pixels are requested HERE, in front of the barrier and the exchange reads (asked
             // for at the point of use, each of the 8 requests per wave and tile stood exposed for a DRAM round trip)
             constexpr int JN_ = M / C::NPART;
+            // folded tile: this round's MFMA tiles are the second half's (8 rows up, TWPX columns to the right)
+            static_assert(!C::FOLD || 2 % C::MTL == 0, "a round holds MFMA tiles of one half");
+            constexpr int FDY = C::FOLD && C::MTL * rnd >= 2 ? -8 : 0, FDX = C::FOLD && C::MTL * rnd >= 2 ? C::TWPX : 0;
             [[maybe_unused]] f32x4 skh[2][JN_], skl[2][JN_];
 #ifndef BSVD_WX_SKIPPF
 #define BSVD_WX_SKIPPF 1
@@ -935,10 +965,10 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
 #pragma unroll
                     for (int sidx = 0; sidx < 2; ++sidx) {
                         const int m = (lane + 64 * sidx) >> 2;
-                        const int oy = oy0 + 4 * (C::MTL * rnd + mtl) + (m >> 3);
+                        const int oy = oy0 + 4 * (C::MTL * rnd + mtl) + (m >> 3) + FDY;
 #pragma unroll
                         for (int jj = 0; jj < JN_; ++jj) {
-                            const int ox = ox0 + M * (m & 7) + part * JN_ + jj;
+                            const int ox = ox0 + M * (m & 7) + part * JN_ + jj + FDX;
                             const bool live = oy < p.Ho && ox < p.Wo && n8 < p.Cout;
                             const int sub = n8 / Cq, c8 = n8 - sub * Cq;
                             const int64_t upix = (int64_t)(2 * oy + (sub >> 1)) * (2 * p.Wo) + (2 * ox + (sub & 1));
@@ -980,7 +1010,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
 #pragma unroll
                     for (int j = 0; j < M; ++j) ov[j][k] = oo[j];
                 }
-                const int oy = oy0 + 4 * (C::MTL * rnd + mtl) + (m >> 3);
+                const int oy = oy0 + 4 * (C::MTL * rnd + mtl) + (m >> 3) + FDY;
 #pragma unroll
                 for (int jj = 0; jj < JN; ++jj) {
                     // (compile-time column index per part keeps ov[] in registers)
@@ -995,7 +1025,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
                         if constexpr (ACT == BSVD_ACT_RELU6) v[k] = __builtin_amdgcn_fmed3f(v[k], 0.f, 6.f);
                         else if constexpr (ACT == BSVD_ACT_RELU) v[k] = fmaxf(v[k], 0.f);
                     }
-                    const int ox = ox0 + M * (m & 7) + jcol;
+                    const int ox = ox0 + M * (m & 7) + jcol + FDX;
                     const bool live = oy < p.Ho && ox < p.Wo && n8 < p.Cout;
                     float *dst;
                     if constexpr (EPI == BSVD_EPI_PS_ADD) {
@@ -1072,6 +1102,12 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
     winox_tile<M, NH, NTW, MT, PERSIST, XF, XCfg<M, NH, NTW, MT, PERSIST>::TR>(p);
 }
 
+#ifndef BSVD_WX_TAIL
+#define BSVD_WX_TAIL 2     // 16-row tile grids whose last row band has <= 8 live rows: 0 nothing special, 1 that band runs the 8-row body, 2 (F(2,3); F(6,3)'s
+                           // transform buffers do not fit two more patch rows: 1) that band is walked by folded tiles, two of its tiles per workgroup
+#endif
+constexpr bool wx_tail_folds(int m) { return BSVD_WX_TAIL == 2 && m == 2; }
+
 // 16-row tile grid whose LAST row band has <= 8 live rows (Ho mod 16 in 1..8: the 135-row layers of a 540 x 960 frame, the 120-row ones of
 // 480 x 856): those workgroups run the 8-row body -- the same instruction sequence per output (bit-identical, like the 8-row tile of
 // small grids), 0.57 of a full tile's time for tiles that are <= half alive.  A wave-uniform branch at the very top, two complete
@@ -1079,15 +1115,22 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M,
 template <int M, int NH, int NTW, bool XF>
 __global__ __launch_bounds__((XCfg<M, NH, NTW, 4, false>::NTHREADS), (XCfg<M, NH, NTW, 4, false>::NW / 4)) void winox_kernel_tail(const ConvParams p)
 {
-    // this workgroup's tile row, decoded like winox_tile does (XCD-contiguous tile ranges, optional reverse walk)
-    const int ntiles = p.frames * p.nty * p.ntx * p.nct;
+    // this workgroup's tile, decoded like winox_tile does (XCD-contiguous tile ranges, optional reverse walk)
+    constexpr bool FOLDS = wx_tail_folds(M);
+    const WxGrid G = wx_grid(p.nty, p.ntx, p.nct, p.Ho, FOLDS);
+    const int ntiles = p.frames * G.per_frame;
     const int bid = blockIdx.x, xcd = bid & 7;
     const int q8 = ntiles >> 3, r8 = ntiles & 7;
     int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     if (p.flip) lid = ntiles - 1 - lid;
-    const int ty = (lid / (p.nct * p.ntx)) % p.nty;
-    if (p.nty >= 2 && p.Ho - ty * 16 <= 8) winox_tile<M, NH, NTW, 2, false, XF, 16>(p);
-    else winox_tile<M, NH, NTW, 4, false, XF, 16>(p);
+    if constexpr (FOLDS) {
+        if (G.fold && lid % G.per_frame >= G.nreg) winox_tile<M, NH, NTW, 4, false, XF, 16, 2>(p);
+        else winox_tile<M, NH, NTW, 4, false, XF, 16, 1>(p);
+    } else {
+        const int ty = (lid / (p.nct * p.ntx)) % p.nty;
+        if (p.nty >= 2 && p.Ho - ty * 16 <= 8) winox_tile<M, NH, NTW, 2, false, XF, 16>(p);
+        else winox_tile<M, NH, NTW, 4, false, XF, 16>(p);
+    }
 }
 
 template <int M, int NH, int NTW, int MT = 4, bool PERSIST = false, bool XF = false>
@@ -1107,14 +1150,13 @@ static int launch_winox_cfg(const ConvParams &pin, hipStream_t stream, char *nam
     p.ntx = (p.Wo + C::TWPX - 1) / C::TWPX;
     p.nty = (p.Ho + C::TR - 1) / C::TR;
     p.nct = (p.Cout + C::BN - 1) / C::BN;
-    const int64_t nblk = (int64_t)p.frames * p.nty * p.ntx * p.nct;
+    constexpr bool TAILK = BSVD_WX_TAIL && MT == 4 && !PERSIST && C::NTHREADS == 512 && (M == 2 || M == 6);
+    const int64_t nblk = (int64_t)p.frames * wx_grid(p.nty, p.ntx, p.nct, p.Ho, TAILK && wx_tail_folds(M)).per_frame;
     if (nblk <= 0 || nblk > 0x7fffffff) { set_error("bsvd_conv3x3: grid of %lld workgroups", (long long)nblk); return -1; }
-#ifndef BSVD_WX_TAIL
-#define BSVD_WX_TAIL 1     // 16-row tile grids whose last row band has <= 8 live rows run that band on the 8-row body (winox_kernel_tail)
-#endif
     // the product's 16-row tile launches are ALL this kernel (one symbol per form in a profile): a grid without such a band never takes
     // the branch
-    if constexpr (BSVD_WX_TAIL && MT == 4 && !PERSIST && C::NTHREADS == 512 && (M == 2 || M == 6)) {
+    if constexpr (TAILK) {
+        static_assert(XCfg<M, NH, NTW, 4, false, wx_tail_folds(M)>::LDS_BYTES == C::LDS_BYTES, "the folded tile's transform buffers fit under the exchange");
         static std::atomic<int> granted_t[MAX_DEVICES];
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&winox_kernel_tail<M, NH, NTW, XF>), C::LDS_BYTES, granted_t);
         if (e != hipSuccess) return (int)e;
@@ -1180,8 +1222,10 @@ int launch_winox(const ConvParams &p, hipStream_t stream, char *name, int name_l
     case 2:
     case 42: {
         using C4 = XCfg<2, 2, 2, 4>;
-        const int64_t per_row = (int64_t)p.frames * ((p.Wo + C4::TWPX - 1) / C4::TWPX) * ((p.Cout + C4::BN - 1) / C4::BN);
-        const int64_t n4 = per_row * ((p.Ho + 15) / 16), n2 = per_row * ((p.Ho + 7) / 8);
+        const int ntx4 = (p.Wo + C4::TWPX - 1) / C4::TWPX, nct4 = (p.Cout + C4::BN - 1) / C4::BN;
+        const int64_t per_row = (int64_t)p.frames * ntx4 * nct4;
+        // (the 16-row grid as it is launched: a short last row band folds -- 256 -> 256 on ONE 135 x 240 frame is 240 + 16 = 256 workgroups, one round)
+        const int64_t n4 = (int64_t)p.frames * wx_grid((p.Ho + 15) / 16, ntx4, nct4, p.Ho, wx_tail_folds(2)).per_frame, n2 = per_row * ((p.Ho + 7) / 8);
         if (p.wino_m == 2 && n4 < 8 * BSVD_CUS && 0.87 * fill(n2) > fill(n4)) return launch_winox_cfg<2, 2, 2, 2>(p, stream, name, name_len);
 #ifdef BSVD_MEASURE
         // (large grids as 256 persistent workgroups, the transform pipeline running across tile boundaries: built, bit-identical, 6-13 %

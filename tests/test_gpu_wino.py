@@ -100,7 +100,9 @@ def test_half_height_tile_is_bit_identical_and_taken_by_grids_that_do_not_fill_t
     from bsvd_amd.netspec import ConvSpec
     from bsvd_amd.schedule import Halo
     rs = np.random.RandomState(5)
-    for cin, H, W, want_half in ((128, 270, 480, False), (256, 135, 240, True)):
+    # (256 -> 256 at 135 x 240 was the case this tile was built for -- 270 workgroups; since the short last row band folds, that launch is
+    #  240 + 16 = 256 workgroups of the full tile, one round: see the folded-band test below.  128 -> 128 on 135 x 240: 128 workgroups, half the chip)
+    for cin, H, W, want_half in ((128, 270, 480, False), (128, 135, 240, True)):
         sp = ConvSpec("l", "l", cin, cin, 1, True, "relu6", 0)
         st = seeded_state([("e0.weight", (16, 4, 3, 3)), ("e0.bias", (16,)), ("l.weight", (cin, cin, 3, 3)),
                            ("l.bias", (cin,)), ("e1.weight", (3, 16, 3, 3)), ("e1.bias", (3,))], 7)
@@ -118,6 +120,84 @@ def test_half_height_tile_is_bit_identical_and_taken_by_grids_that_do_not_fill_t
             y1 = gex.conv(sp, x, Halo(x, cin, sp.fold), Halo(x, cin, 0))     # frame 5's neighbours = the same frame
             assert gex.last_variant.endswith("[8 rows]")
             assert torch.equal(y10[5:6], y1)
+
+
+FOLD_CASES = [
+    # cin, cout, tsm, epi, T, H, W: 16-row grids whose last row band has <= 8 live rows
+    (128, 128, True, 0, 1, 24, 16),       # one tile column: the folded tile's second half lies outside the image
+    (128, 128, True, 0, 3, 23, 40),       # three tile columns (odd: the last folded tile is half dead), 7 live rows, three temporal sources
+    (256, 256, True, 0, 2, 17, 64),       # one live row in the band, two channel tiles
+    (256, 512, False, 1, 2, 20, 33),      # PixelShuffle + skip through the folded epilogue, four channel tiles
+    (128, 256, False, 1, 1, 40, 50),      # two full bands above the folded one
+]
+
+
+@pytest.mark.parametrize("xf32", [False, True])
+@pytest.mark.parametrize("cin,cout,tsm,epi,T,H,W", FOLD_CASES)
+def test_folded_last_row_band_is_bit_identical_to_the_half_height_tile(cin, cout, tsm, epi, T, H, W, xf32):
+    """F(2,3) on a 16-row tile grid whose last row band has <= 8 live rows: that band's tiles are walked two per workgroup, as the two 8-row
+    halves of one 16-row tile (conv3x3_winox.hip: XCfg::FOLD, wx_grid) -- 256 -> 256 on one 135 x 240 frame is then 256 workgroups, one round on
+    256 CUs.  Same instruction sequence per output as every other tile: bit-identical to the 8-row tile (which these small grids take with
+    wino_m = 2; 42 = never the 8-row tile = the folded grid), with fp16-pair and plain-fp32 tensors, and within the oracle tolerance."""
+    import ctypes
+    from bsvd_amd import _lib
+    from bsvd_amd.netspec import ConvSpec
+    from bsvd_amd.schedule import Halo
+    rs = np.random.RandomState(cin + H + W)
+    sp = ConvSpec("l", "l", cin, cout, 1, tsm, "relu6" if epi == 0 else "none", epi)
+    st = seeded_state([("e0.weight", (16, 4, 3, 3)), ("e0.bias", (16,)), ("l.weight", (cout, cin, 3, 3)),
+                       ("l.bias", (cout,)), ("e1.weight", (3, 16, 3, 3)), ("e1.bias", (3,))], 7)
+    gex, oex = _exec(_Net(sp), st, "wino2"), OracleExecutor(st, double=True)
+    gex.force_x_f32 = gex.force_y_f32 = xf32
+    x = torch.from_numpy(rs.standard_normal((T, H, W, cin)).astype(np.float32))
+    if not xf32:
+        x = from_split(to_split(x))
+    enc = (lambda t: t.to(_dev())) if xf32 else (lambda t: to_split(t).to(_dev()))
+    dec = (lambda t: t.cpu()) if xf32 else (lambda t: from_split(t.cpu()))
+    extra = extra_dev = None
+    eps = 0
+    if epi == 1:
+        extra = from_split(to_split(torch.from_numpy(rs.standard_normal((T, 2 * H, 2 * W, cout // 4)).astype(np.float32))))
+        extra_dev, eps = to_split(extra).to(_dev()), cout // 4
+    hp = hn = hpd = hnd = None
+    if tsm:
+        q = (lambda t: t) if xf32 else (lambda t: from_split(to_split(t)))
+        hp = Halo(q(torch.from_numpy(rs.standard_normal((H, W, sp.fold)).astype(np.float32))), sp.fold, 0)
+        hn = Halo(q(torch.from_numpy(rs.standard_normal((H, W, sp.fold)).astype(np.float32))), sp.fold, 0)
+        hpd, hnd = Halo(enc(hp.t), sp.fold, 0), Halo(enc(hn.t), sp.fold, 0)
+    outs = {}
+    for code in (2, 42):
+        a, y = gex.build_args(sp, enc(x), hpd, hnd, extra_dev, eps, 1)
+        a.wino_m = code
+        buf = ctypes.create_string_buffer(96)
+        _lib.check(gex.lib.bsvd_conv3x3_variant(ctypes.byref(a), buf, 96), "variant")
+        _lib.check(gex.lib.bsvd_conv3x3(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "conv")
+        torch.cuda.synchronize()
+        outs[code] = (y, buf.value.decode())
+    assert outs[2][1].endswith("[8 rows]" + ("[f32 in]" if xf32 else "")) and "[8 rows]" not in outs[42][1], (outs[2][1], outs[42][1])
+    assert torch.equal(outs[2][0], outs[42][0])
+    err = maxabs(dec(outs[42][0]).numpy(), oex.conv(sp, x, hp, hn, extra, eps, 1).numpy())
+    print("folded band, layer %s f32 %s: max-abs %.3e" % ((cin, cout, tsm, epi, T, H, W), xf32, err))
+    assert err < TIGHT
+
+
+def test_one_135_row_frame_of_the_256_channel_layers_is_one_round_of_full_tiles():
+    """the launch the folded band was built for: 256 -> 256 on ONE 135 x 240 frame (the quarter-resolution temporal layers of a 540 x 960 stream
+    step) -- 8 full bands x 15 x 2 + 8 x 2 folded = 256 workgroups, so wino_m = 2 keeps the full tile; same bits as that frame inside a clip."""
+    from bsvd_amd.netspec import ConvSpec
+    from bsvd_amd.schedule import Halo
+    rs = np.random.RandomState(11)
+    cin = 256
+    sp = ConvSpec("l", "l", cin, cin, 1, True, "relu6", 0)
+    st = seeded_state([("e0.weight", (16, 4, 3, 3)), ("e0.bias", (16,)), ("l.weight", (cin, cin, 3, 3)),
+                       ("l.bias", (cin,)), ("e1.weight", (3, 16, 3, 3)), ("e1.bias", (3,))], 7)
+    x = to_split(torch.from_numpy(rs.standard_normal((1, 135, 240, cin)).astype(np.float32))).to(_dev())
+    gex = _exec(_Net(sp), st, "wino2")
+    gex.record_variants = True
+    y1 = gex.conv(sp, x, Halo(x, cin, sp.fold), Halo(x, cin, 0))
+    assert "[8 rows]" not in gex.last_variant, gex.last_variant
+    y10 = gex.conv(sp, x.expand(10, -1, -1, -1).contiguous())
+    assert torch.equal(y10[5:6], y1)
 
 
 def test_product_library_has_no_measurement_variants():
