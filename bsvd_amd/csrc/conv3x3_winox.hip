@@ -687,6 +687,12 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
     __syncthreads();
 
     const unsigned a_lane = (unsigned)(xi * 4 * C::PLANE + lh * C::PLANE + li * 16);
+#ifndef BSVD_WX_SPRIO
+#define BSVD_WX_SPRIO 0    // wave priority in the K loop (MI355X_MICROARCH "two waves per SIMD": VALU issue is arbitrated by priority, then age):
+                           //   1 / 2: the second- / first-dispatched half of the workgroup at s_setprio 1 for the whole loop;  3: every wave's MFMA steps at 1
+#endif
+    if constexpr (BSVD_WX_SPRIO == 1) { if (wid >= C::NW / 2) __builtin_amdgcn_s_setprio(1); }
+    if constexpr (BSVD_WX_SPRIO == 2) { if (wid < C::NW / 2) __builtin_amdgcn_s_setprio(1); }
 #ifndef BSVD_WX_PHASE
 #define BSVD_WX_PHASE 0    // which waves run the chunk's phases in opposite order: 0 (wid >> 2), 1 wid, 2 (wid >> 1)   (A/B: who shares a SIMD?)
 #endif
@@ -883,7 +889,9 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
         if (!(BSVD_WX_ABL & 1) && phase != 0) xform(XFin{});
         __builtin_amdgcn_sched_barrier(0);
         [[maybe_unused]] const unsigned long long t1 = WXT_NOW();
+        if constexpr (BSVD_WX_SPRIO == 3) __builtin_amdgcn_s_setprio(1);
         if (!(BSVD_WX_ABL & 2)) mfma_phase(std::integral_constant<int, C::MT>{});
+        if constexpr (BSVD_WX_SPRIO == 3) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         [[maybe_unused]] const unsigned long long t2 = WXT_NOW();
         if (!(BSVD_WX_ABL & 1) && phase == 0) xform(XFin{});
@@ -896,6 +904,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
     }
     }
 
+    if constexpr (BSVD_WX_SPRIO == 1 || BSVD_WX_SPRIO == 2) __builtin_amdgcn_s_setprio(0);
     tl_epi = WXT_NOW();
     // ---- epilogue: NRND rounds of publish -> finish
     const int Cq = p.Cout >> 2;
