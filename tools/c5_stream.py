@@ -78,6 +78,10 @@ for blk in (m.net.temp1, m.net.temp2):
         aargs.frames, aargs.H, aargs.W, aargs.Cin, aargs.Cout, aargs.stride = 1, h, w, sp.cin_pad, sp.cout_pad, sp.stride
         aargs.fold, aargs.act, aargs.epilogue, aargs.dtype = sp.fold, _lib.ACT[sp.act], sp.epilogue, ex.dtype
         aargs.resid_ch = 3 if sp.epilogue == 2 else 0
+        aargs.w_wino_packed = 256
+        aargs.wino_m = ex.packed.wino_layer_abi.get(sp.key, 0)            # the form the pack chose for this layer (0: direct tile)
+        aargs.x_f32 = 1 if sp.key in getattr(ex.packed, "f32_in", ()) else 0
+        aargs.y_f32 = 1 if sp.key in getattr(ex.packed, "f32_out", ()) else 0
         if sp.key == "temp1.inc.convblock.0":
             aargs.x_planar_ch = sp.cin
         if sp.key == "temp2.outc.convblock.3":
