@@ -551,7 +551,13 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
     // (a quarter of its lanes active: more instructions per wave, but every wave the same, and all of it in the MFMAs' shadow; a rotating
     // wave's extra item held the chunk barrier up for ~2000 cycles of 7900)
     // The half-height tile (10 patch rows): one full item per lane instead of two, the same left-over blocks (rows 8, 9).
-    constexpr bool BAL = BSVD_WX_ILV == 2 && C::NTHREADS != 768;
+    // ILV3: the transform of the NEXT chunk goes into each wave's OWN MFMA stream, one or two instructions behind every MFMA, every micro-step
+    // pinned with scheduling fences (BSVD_WX_ILV = 3; F(2,3), plain-fp32 input, 512-thread workgroups).  Background: r04's microbenchmark and
+    // timeline -- a wave's VALU beside ANOTHER wave's MFMAs on the same SIMD interferes destructively (an MFMA wave beside a VALU wave: 3x
+    // the serial time; in the kernel the second wave's MFMA steps run at 35 % rate while the first one transforms), while VALU behind a wave's
+    // own MFMAs costs about its issue slot (8 x (MFMA + 2 VALU): 592 against 512 cycles).
+    constexpr bool ILV3 = BSVD_WX_ILV == 3 && XF && M == 2 && C::MT == 4 && C::NTHREADS == 512 && CH == 2 && !PERSIST;
+    constexpr bool BAL = (BSVD_WX_ILV == 2 && C::NTHREADS != 768) || ILV3;
 #ifndef BSVD_WX_DEADROWS
 #define BSVD_WX_DEADROWS 0     // 1: a tile with <= 8 image rows (the last tile row of a 135- or 120-row layer) runs its two upper MFMA tiles only: half the MFMA
                                // steps, the transform of patch rows 0 .. 9 only, one epilogue round; bit-identical.  Measured: 256 -> 256 at 135 rows -1.7 %,
@@ -784,6 +790,93 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
         };
         // (one copy of the MFMA steps between two conditional transforms: an if / else with the phases in opposite orders made the
         //  register allocator carry the accumulators in two register sets and spill 60-260 registers)
+        if constexpr (ILV3) {
+            static_assert(NMAIN == 3 && NROT == 0 && NDW == 1 && A == 4 && NTW == 2, "fine interleave: three items per lane, 72 MFMAs per chunk");
+            const int tl = lane_id();
+            // chunk cb + 1 + PP (behind the tile's last chunk: zero-size descriptors -- the micro-steps run unconditionally, no branch in the stream;
+            // what they transform behind the last chunk is zeros into a buffer nobody reads)
+            XChunkSrc cl;
+            if (cb + 1 + PP >= ncb) cl = x_chunk_src(next_tile(), cb + 1 + PP - ncb);
+            else cl = x_chunk_src(T, cb + 1 + PP);
+            // in-flight state of the ONE item being worked on
+            float bt0[A], bt1[A];
+            unsigned hp = 0, lp = 0, lbase = 0;
+            int lgx0 = 0;
+            unsigned char *dst = nullptr;
+            unsigned char *const dummy = xsm + 2 * C::V_BUF + (tl & 15) * 4;       // where an inactive lane's stores go (no exec-mask branch)
+            static_assert(2 * C::V_BUF + 16 * C::PLANE <= C::LDS_BYTES, "dummy store area behind the V buffers");
+            // micro-step m of item k: 0 geometry + store address | 1, 2 BT of channel 0, 1 | 3 + 2 i re-split of position i | 4 + 2 i its two stores |
+            //                         11 geometry of the request | 12 + i request of position i (chunk cb + 1 + PP, into the same registers)
+            auto micro = [&](auto k_, auto m_) __attribute__((always_inline)) {
+                constexpr int k = decltype(k_)::value, m = decltype(m_)::value;
+                Raw &r = raw[setv][k];
+                if constexpr (m == 0) {
+                    int row, qb, g, sub;
+                    item_geom(main_E(k, tl), row, qb, g, sub);
+                    unsigned char *d = pnext + qb * C::PLANE + (row * 8 + g) * 16 + sub;
+                    dst = main_active(k, tl) ? d : dummy;
+                } else if constexpr (m == 1 || m == 2) {
+                    float d[A];
+#pragma unroll
+                    for (int i = 0; i < A; ++i) d[i] = __builtin_bit_cast(float, m == 1 ? r.h[i][0] : r.l[i][0]);
+                    if constexpr (m == 1) F::input(d, bt0); else F::input(d, bt1);
+                } else if constexpr (m < 11 && (m & 1)) {
+                    constexpr int i = (m - 3) / 2;
+                    split_pair(bt0[i], bt1[i], hp, lp, mixk);
+                } else if constexpr (m < 11) {
+                    constexpr int i = (m - 4) / 2;
+                    *reinterpret_cast<unsigned *>(dst + i * 4 * C::PLANE) = hp;
+                    *reinterpret_cast<unsigned *>(dst + i * 4 * C::PLANE + 2 * C::PLANE) = lp;
+                } else if constexpr (m == 11) {
+                    int row, qb, g, sub;
+                    item_geom(main_E(k, tl), row, qb, g, sub);
+                    lgx0 = cl.ox0 - 1 + M * g;
+                    if constexpr (C::FOLD) {
+                        const bool up = row >= C::PRH;
+                        row = up ? row - C::PRH : row;
+                        lgx0 = up ? lgx0 + C::TWPX : lgx0;
+                    }
+                    lbase = main_active(k, tl) ? (unsigned)((cl.oy0 - 1 + row) * p.W + lgx0) * cl.ps4 + (unsigned)(qb * 32 + 2 * sub) : BSVD_WX_OOB;
+                } else {
+                    constexpr int i = m - 12;
+                    const u32x2 v = buf_load2(cl.rs, (unsigned)(lgx0 + i) < (unsigned)p.W ? lbase + (unsigned)i * cl.ps4 : BSVD_WX_OOB, cl.soff);
+                    r.h[i][0] = v[0]; r.l[i][0] = v[1];
+                }
+            };
+            f32x4 afr[2][2];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) afr[0][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE);
+            static_for<0, 3 * C::MT>([&](auto s_) __attribute__((always_inline)) {
+                constexpr int S_ = decltype(s_)::value, KY = S_ / C::MT, mt = S_ % C::MT;
+                const f32x4 (&b)[NTW][2] = bring[KY];
+                if constexpr (S_ < 3 * C::MT - 1) {
+                    constexpr int KY1 = (S_ + 1) / C::MT, mt1 = (S_ + 1) % C::MT;
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt)
+                        afr[(S_ + 1) & 1][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE + C::frag_row(mt1, KY1) * 128);
+                }
+                const f32x4 (&a)[2] = afr[S_ & 1];
+                static_for<0, 3 * NTW>([&](auto j_) __attribute__((always_inline)) {
+                    constexpr int J = decltype(j_)::value, pass = J / NTW, nt = J % NTW, Q = S_ * 3 * NTW + J;
+                    __builtin_amdgcn_sched_barrier(0);
+                    {
+                        const f16x8 bv = __builtin_bit_cast(f16x8, b[nt][pass == 1 ? 1 : 0]);
+                        const f16x8 av = __builtin_bit_cast(f16x8, a[pass == 0 ? 1 : 0]);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv, av, acc[mt][nt], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // two of every three MFMAs carry a micro-step: 48 = 3 items x 16
+                    if constexpr (Q % 3 < 2) {
+                        constexpr int idx = (Q / 3) * 2 + Q % 3;
+                        micro(std::integral_constant<int, idx / 16>{}, std::integral_constant<int, idx % 16>{});
+                    }
+                });
+                if constexpr (mt == C::MT - 1) { __builtin_amdgcn_sched_barrier(0); load_b((cb + 1) * 3 + KY, bring[KY]); }      // this slab's last use was the step above
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(BSVD_WX_ABL & 8)) __syncthreads();
+            continue;
+        }
         if constexpr (BSVD_WX_ILV == 2) {
             // Manual coarse interleave, pinned with scheduling fences: the 12 (ky, mt) steps of 3 NTW MFMAs each, and behind every step one
             // slot of the wave's OWN transform work.  (A wave streaming MFMAs leaves the other wave of its SIMD about one VALU issue per MFMA
