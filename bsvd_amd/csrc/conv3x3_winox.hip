@@ -321,8 +321,15 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
     //  and cost more than it saved (the reads' lgkmcnt(0) waits sit inside the MFMA steps).  Measured 6-13 % slower than one tile per
     //  workgroup; kept for the record, never selected: BSVD_WX_PERSIST_MIN.)
     auto next_tile = [&]() __attribute__((always_inline)) {
+#ifndef BSVD_WX_PFNEXT
+#define BSVD_WX_PFNEXT 0   // N > 0: the requests behind a tile's last chunk go to the first chunks (and weight slabs) of the tile N places further down this
+                           // XCD's list -- the one the CU's NEXT workgroup will most likely run (32 CUs per XCD) -- and are never consumed: an L2 prefetch
+                           // for that workgroup's prologue (8-9 K cycles of a 68-114 K tile, most of it the first memory round trip)
+#endif
         if constexpr (PERSIST) {
             return decode_tile(jt + xcd_wgs);
+        } else if constexpr (BSVD_WX_PFNEXT > 0) {
+            return decode_tile(jt + BSVD_WX_PFNEXT);
         } else {              // no next tile: T with zero-size sources (no decoding -- this sits in the K loop's last iterations)
             XTile t = T;
             t.S.cur_bytes = t.S.prev_bytes = t.S.next_bytes = 0u;
@@ -783,7 +790,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
             const int tl = lane_id();
             // (one tile per workgroup: nothing behind the tile's last chunk -- its transform and the requests of the last PP + 1 iterations
             //  would be zeros from zero-size descriptors, a whole transform phase per tile for nothing)
-            constexpr bool TS_FIN = BSVD_WX_TAILSKIP && !PERSIST, TS_LD = TS_FIN && M == 2 && !BSVD_WX_UNCOND;      // (F(6,3) with the request skip too: 25 spills)
+            constexpr bool TS_FIN = BSVD_WX_TAILSKIP && !PERSIST, TS_LD = TS_FIN && M == 2 && !BSVD_WX_UNCOND && !(BSVD_WX_PFNEXT > 0);      // (F(6,3) with the request skip too: 25 spills)
             if constexpr (XP & 1) if (!TS_FIN || cb + 1 < ncb) chunk_finish(cb + 1, pnext, setv, PAll{}, tl);
             if constexpr (XP & 2) if (!(BSVD_WX_ABL & 64) && (!TS_LD || cb + 1 + PP < ncb)) chunk_load(cb + 1 + PP, setv, PAll{}, tl);
             if (BSVD_WX_PRIO) __builtin_amdgcn_s_setprio(0);

@@ -118,7 +118,9 @@ typedef struct BsvdConvArgs {
      * kernel (conv3x3_winox.hip, one transformed position per wave) with the TRANSFORMED weights of bsvd_pack_weights_wino();
      * w_packed is then ignored (may be NULL).  wino_m:
      *    2 | 6    F(2,3) | F(6,3).  The kernel picks its half-height pixel tile for grids that do not fill the chip (single-frame
-     *             launches); both tiles compute every output with the same instruction sequence (bit-identical).
+     *             launches); both tiles compute every output with the same instruction sequence (bit-identical).  On the 16-row
+     *             tile grid a last row band with <= 8 live rows (Ho mod 16 in 1 .. 8) is walked two tiles per workgroup (F(2,3):
+     *             folded tiles) or on the 8-row body (F(6,3)) -- again the same instruction sequence per output.
      *   42 | 46   the same two forms, never on the half-height tile: for launches that run beside another stream's or graph
      *             branch's kernels (idle CUs are not idle there).  Same bits as 2 | 6.
      *   Other codes (F(4,3), forced tiles, 4-wave workgroups, the persistent form, the all-positions-per-wave kernel) exist in
