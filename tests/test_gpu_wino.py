@@ -181,6 +181,44 @@ def test_folded_last_row_band_is_bit_identical_to_the_half_height_tile(cin, cout
     assert err < TIGHT
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_folded_band_random_shapes_bitwise(seed):
+    """seeded random layers on 16-row grids with a short last band (any column count, 1-3 frames, both tensor formats, with and without the
+    reverse tile walk the engine alternates between layers): folded grid (wino_m 42) == 8-row tile (wino_m 2) bit for bit."""
+    import ctypes
+    from bsvd_amd import _lib
+    from bsvd_amd.netspec import ConvSpec
+    from bsvd_amd.schedule import Halo
+    rs = np.random.RandomState(1000 + seed)
+    cin = int(rs.choice([128, 256]))
+    cout = int(rs.choice([128, 256]))
+    H = 16 * int(rs.randint(1, 4)) + int(rs.randint(1, 9))
+    W = int(rs.randint(8, 90))
+    T = int(rs.randint(1, 4))
+    xf32 = bool(rs.randint(0, 2))
+    sp = ConvSpec("l", "l", cin, cout, 1, True, "relu6", 0)
+    st = seeded_state([("e0.weight", (16, 4, 3, 3)), ("e0.bias", (16,)), ("l.weight", (cout, cin, 3, 3)),
+                       ("l.bias", (cout,)), ("e1.weight", (3, 16, 3, 3)), ("e1.bias", (3,))], 7)
+    gex = _exec(_Net(sp), st, "wino2")
+    gex.force_x_f32 = gex.force_y_f32 = xf32
+    enc = (lambda t: t.to(_dev())) if xf32 else (lambda t: to_split(t).to(_dev()))
+    x = enc(torch.from_numpy(rs.standard_normal((T, H, W, cin)).astype(np.float32)))
+    hp = Halo(enc(torch.from_numpy(rs.standard_normal((H, W, sp.fold)).astype(np.float32))), sp.fold, 0)
+    hn = Halo(enc(torch.from_numpy(rs.standard_normal((H, W, sp.fold)).astype(np.float32))), sp.fold, 0)
+    outs = []
+    for code in (2, 42):
+        for flip in (0, 1):
+            a, y = gex.build_args(sp, x, hp, hn)
+            a.wino_m = code
+            a.tile_order = flip
+            _lib.check(gex.lib.bsvd_conv3x3(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "conv")
+            torch.cuda.synchronize()
+            outs.append(y)
+    print("fold fuzz %d: %d->%d %dx%dx%d f32 %s" % (seed, cin, cout, T, H, W, xf32))
+    for y in outs[1:]:
+        assert torch.equal(outs[0], y)
+
+
 def test_one_135_row_frame_of_the_256_channel_layers_is_one_round_of_full_tiles():
     """the launch the folded band was built for: 256 -> 256 on ONE 135 x 240 frame (the quarter-resolution temporal layers of a 540 x 960 stream
     step) -- 8 full bands x 15 x 2 + 8 x 2 folded = 256 workgroups, so wino_m = 2 keeps the full tile; same bits as that frame inside a clip."""

@@ -16,7 +16,7 @@ for prec in ("f16x3", "fp32"):
                                            interm_ch=30, blind=True), precision=prec).to(dev).eval()
     for psz, fbl in ((11, 2), (-1, 0)):
         with torch.no_grad():
-            bsvd_amd.denoise_seq(seq[:13], None, psz, m, future_buffer_len=fbl)
+            bsvd_amd.denoise_seq(seq if psz < 0 else seq[:13], None, psz, m, future_buffer_len=fbl)      # warm-up (whole clip at once: its buffers too)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             out = bsvd_amd.denoise_seq(seq, None, psz, m, future_buffer_len=fbl)
             torch.cuda.synchronize()
