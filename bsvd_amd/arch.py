@@ -330,7 +330,7 @@ class BSVD(_HipNet):
                     one HIP graph (default True; same results, bit for bit).
       stream_rings / stream_graphs : the stream schedule runs on preallocated ring buffers and replays each step as a
                     HIP graph (both default True; False = the allocating layer-by-layer path / batched launches).
-      stream_chunk : frames per pipeline step of streaming_forward ('auto': up to 8 as memory allows; 1 = the reference's
+      stream_chunk : frames per pipeline step of streaming_forward ('auto': 2 when the rings fit -- within 1 % of 8 at a quarter of the memory; 1 = the reference's
                     frame-by-frame pipeline).  feedin_one_element always runs one frame per step.
       precision   : 'f16x3' (split-fp16 3-pass MFMA with fp32 accumulation: fp32-class accuracy -- 2-6e-5 max-abs on
                     bsvd_c64, budget 1e-3 -- at ~3x the throughput; needs 64-channel or 128k-channel temporal-fusion layers:
@@ -437,9 +437,13 @@ class BSVD(_HipNet):
             self._stream_engs[chunk] = eng
         return eng
 
+    # 'auto' never takes more frames per step than this: at 540 x 960 a step of 8 frames holds 76.7 GB of rings for +0.9 % over a step of 2
+    # (19 GB; profiles/r05_stream_modes_540x960.json) -- the smallest chunk within 1 % of the best.  An explicit stream_chunk=4 / 8 still runs.
+    AUTO_CHUNK_MAX = 2
+
     def _pick_chunk(self, F, H, W):
-        """Frames per pipeline step of streaming_forward: ``stream_chunk`` if given, else the largest of 8/4/2/1 whose rings
-        fit half of the free HBM (540x960: 9.7 GB per frame of chunk; 1080p: 39 GB)."""
+        """Frames per pipeline step of streaming_forward: ``stream_chunk`` if given, else AUTO_CHUNK_MAX (2) when its rings fit half of
+        the free HBM (540x960: 9.7 GB per frame of chunk; 1080p: 39 GB), else 1."""
         if self.stream_chunk != "auto":
             return max(1, min(int(self.stream_chunk), F))
         from .stream_plan import ring_bytes_estimate
@@ -447,9 +451,11 @@ class BSVD(_HipNet):
         free, _ = torch.cuda.mem_get_info(dev)
         free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
         held = sum(e.ring_bytes for e in self._stream_engs.values())
-        for n in (8, 4, 2):
+        n = self.AUTO_CHUNK_MAX
+        while n >= 2:
             if n <= F and ring_bytes_estimate(self.net, H, W, n) <= 0.5 * (free + held):
                 return n
+            n //= 2
         return 1
 
     def prepare_stream(self, H, W, all_flush_phases=False, dtype=torch.float32):

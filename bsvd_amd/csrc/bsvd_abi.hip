@@ -364,7 +364,7 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
     p.pre_w = nullptr; p.pre_bias = nullptr; p.pre_cin = 0; p.pre_act = 0;
     p.x_f32 = a->x_f32 ? 1 : 0; p.y_f32 = a->y_f32 ? 1 : 0;
     if (a->x_f32 && !(a->dtype == BSVD_F16X3 && a->w_wino_packed)) { set_error("bsvd_conv3x3: x_f32 is the Winograd form's input option (BSVD_F16X3 + w_wino_packed)"); return -21; }
-    if (a->y_f32 && (a->dtype != BSVD_F16X3 || a->y_planar_ch > 0 || a->epilogue == BSVD_EPI_RESID || a->pre_w_packed || a->head_w_packed ||
+    if (a->y_f32 && (a->dtype != BSVD_F16X3 || a->y_planar_ch > 0 || a->x_planar_ch > 0 || a->epilogue == BSVD_EPI_RESID || a->pre_w_packed || a->head_w_packed ||
                      (a->epilogue == BSVD_EPI_PS_ADD && !a->w_wino_packed))) {
         set_error("bsvd_conv3x3: y_f32 needs BSVD_F16X3 and a PLAIN NHWC layer (direct or Winograd form) or a PS_ADD layer of the Winograd form"); return -21;
     }
@@ -376,7 +376,10 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
         if (a->x_planar_ch > 0 || a->head_w_packed) { set_error("bsvd_conv3x3: w_wino_packed: not with a planar / fused entry"); return -19; }
         if (const char *why = wino_unsupported(p, a->stride)) { set_error("bsvd_conv3x3: w_wino_packed (F(%d,3)): %s", a->wino_m, why); return -19; }
 #ifdef BSVD_MEASURE
-        if (p.wino_m >= 10 && p.wino_m < 20) return launch_wino(p, (hipStream_t)stream, name, name_len);
+        if (p.wino_m >= 10 && p.wino_m < 20) {        // the all-positions-per-wave kernel (conv3x3_wino.hip) knows fp16 pairs only
+            if (a->x_f32 || a->y_f32) { set_error("bsvd_conv3x3: x_f32 / y_f32 are not available for wino_m %d", p.wino_m); return -21; }
+            return launch_wino(p, (hipStream_t)stream, name, name_len);
+        }
 #endif
         return launch_winox(p, (hipStream_t)stream, name, name_len);
     }
@@ -384,8 +387,10 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
         if (a->dtype != BSVD_F16X3) { set_error("bsvd_conv3x3: the fused pair (pre_w_packed) is a BSVD_F16X3 kernel"); return -20; }
         if (a->x_planar_ch > 0 || a->head_w_packed) { set_error("bsvd_conv3x3: pre_w_packed: not with a planar input / fused entry"); return -20; }
         if (a->stride != 1 || a->fold != 0 || a->epilogue == BSVD_EPI_PS_ADD) { set_error("bsvd_conv3x3: fused pair needs stride 1, fold 0, PLAIN / RESID"); return -20; }
-        if (a->pre_cin <= 0 || (a->pre_cin & 15) || (a->Cin & 31) || a->Cout > 64) {
-            set_error("bsvd_conv3x3: fused pair needs pre_cin %% 16 == 0, Cin %% 32 == 0, Cout <= 64 (pre_cin %d, Cin %d, Cout %d)", a->pre_cin, a->Cin, a->Cout); return -20;
+        // (Cin <= 64: the kernel carries TWO 32-channel pairs of the first conv's output -- pair 0 in the patch buffers, pair 1 in registers;
+        //  a wider middle tensor would refill chunks 4.. with pair 1's data: refused, never silently wrong)
+        if (a->pre_cin <= 0 || (a->pre_cin & 15) || (a->Cin & 31) || a->Cin > 64 || a->Cout > 64) {
+            set_error("bsvd_conv3x3: fused pair needs pre_cin %% 16 == 0, Cin = 32 or 64, Cout <= 64 (pre_cin %d, Cin %d, Cout %d)", a->pre_cin, a->Cin, a->Cout); return -20;
         }
         if (a->pre_act < BSVD_ACT_NONE || a->pre_act > BSVD_ACT_RELU6) { set_error("bsvd_conv3x3: pre_act %d", a->pre_act); return -20; }
         if (!a->pre_bias || (((uintptr_t)a->pre_w_packed) & 15) || (((uintptr_t)a->pre_bias) & 15) || (((uintptr_t)a->x) & 15) || (a->x_frame_stride & 3)) {

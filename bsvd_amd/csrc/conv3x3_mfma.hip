@@ -44,9 +44,6 @@
 #include "bsvd_internal.h"
 
 // tuning knobs (compile-time; the defaults are the measured best)
-#ifndef BSVD_TUNE_NT_STORE
-#define BSVD_TUNE_NT_STORE 0       // 1: split epilogue writes with the nontemporal hint
-#endif
 #ifndef BSVD_TUNE_ALIGN
 #define BSVD_TUNE_ALIGN 1      // 1: 256-B aligned LDS patch row pitch (conflict-free A reads; +0.5 % in interleaved A/B)
 #endif
@@ -58,9 +55,6 @@
 #endif
 #ifndef BSVD_ABL
 #define BSVD_ABL 0             // TIMING-ONLY ablations of the prefetching K loop (results are wrong): 1 no chunk barrier, 2 no patch slices, 4 no weight loads, 8 half the weight loads (lo := hi), 16 all weight loads from two L1-resident slabs, 32 split epilogue without its stores, 64 split epilogue without the conversion, 128 split epilogue storing lane-contiguous 2-KB runs, 256 pixel fragments read from LDS once per chunk instead of once per tap
-#endif
-#ifndef BSVD_TUNE_PASS_ORDER
-#define BSVD_TUNE_PASS_ORDER 0 // MFMA order inside a pass of the prefetching loops: 0 pixel-tile major, 1 channel-tile major
 #endif
 #ifndef BSVD_TUNE_ZSKIP
 #define BSVD_TUNE_ZSKIP 1      // 128-accumulator split tiles leave the all-zero temporal-shift chunks of a clip's first / last frame out of the K loop
@@ -74,35 +68,12 @@
 #ifndef BSVD_TUNE_APF
 #define BSVD_TUNE_APF 1        // split DBUF tiles that request the NEXT tap's pixel fragments in the middle of the current tap: 0 none, 1 the exit tile (NT == 1), 2 all, 3 fat tiles
 #endif
-#ifndef BSVD_TUNE_QPL
-#define BSVD_TUNE_QPL 5        // quad-planar LDS patch ([row][16-B channel quad][column], row pitch a multiple of 256 B), per tile family:
-                               //   bit 0  the 256-px x 64-ch tile <2,2,4,1,1> and the exit tile <2,1,4,1,1>   (r03: bank conflicts 0.46 / 0.49 -> 0.06 / 0.00
-                               //          of the LDS cycles, 6.25 -> 6.22 ms per clip: the conflicts were not what these tiles wait for)
-                               //   bit 1  the stride-2 tile (even / odd columns in separate planes): conflicts 0.44 -> 0.15, but 2.29 -> 2.34 ms: off
-                               //   bit 2  the 128-px x 32-ch wave tile <4,1,2,2,1> of the 64-channel layers (8 pixel-fragment reads per 12 MFMAs:
-                               //          this one needs conflict-free reads -- 6.42 -> 5.94 ms per clip against <2,2,4,1,1>, r03)
-                               //   bit 3  the 128-channel stride-1 tiles (already conflict-free in the padded layout at a 1536-B pitch): 20.55 -> 20.70 ms: off
-#endif
-#ifndef BSVD_TUNE_PRIO
-#define BSVD_TUNE_PRIO 0       // s_setprio experiment: 1 = epilogue at priority 2, 2 = prologue + epilogue at priority 2, 3 = K loop at priority 2
-#endif
-#ifndef BSVD_TUNE_S2_DBUF
-#define BSVD_TUNE_S2_DBUF 0    // 1: split-fp16 stride-2 tile with a double-buffered (swizzled) patch at 2 workgroups per CU
-#endif
-#ifndef BSVD_TUNE_D
-#define BSVD_TUNE_D 1          // patch slices stored D (1|2) taps after their load was issued
-#endif
 
-// patch-slice register ring of the K loop: loaded into slot tap%3, stored BSVD_TUNE_D taps later
-#if BSVD_TUNE_D == 2
-#define S_OLD0 s1
-#define S_OLD1 s2
-#define S_OLD2 s0
-#else
+// patch-slice register ring of the K loop: loaded into slot tap % 3, stored one tap later (two taps later: -0.1 %, r02)
+#define BSVD_SLICE_D 1
 #define S_OLD0 s2
 #define S_OLD1 s0
 #define S_OLD2 s1
-#endif
 
 namespace bsvd {
 
@@ -134,9 +105,12 @@ struct ConvCfg {
     // too: 8 adjacent lanes = 2 columns x 4 quads, and the 288-B (stride 2: 272-B) plane pitch puts the quads 32 B (16 B)
     // apart modulo the 128-B write bank row.  64 B per pixel instead of 80: 4/5 of the padded layout's LDS.  Stride 2: a tap
     // reads every other column, so even and odd columns get separate planes ([row][quad][parity][column / 2]).
-    static constexpr bool QPL = (STRIDE == 2) ? (BSVD_TUNE_QPL & 2) != 0
-                                : (MT == 2 && WM == 4) ? (BSVD_TUNE_QPL & 1) != 0
-                                : (NT == 1)            ? (BSVD_TUNE_QPL & 4) != 0 : (BSVD_TUNE_QPL & 8) != 0;
+    // quad-planar LDS patch ([row][16-B channel quad][column], row pitch a multiple of 256 B), per tile family (r03 / r05 records):
+    //   the 256-px x 64-ch tile <2,2,4,1,1> and the exit tile <2,1,4,1,1>: yes (bank conflicts 0.46 / 0.49 -> 0.06 / 0.00 of the LDS cycles, times =)
+    //   the 128-px x 32-ch wave tile <4,1,2,2,1> of the 64-channel layers: yes (8 pixel-fragment reads per 12 MFMAs need conflict-free reads: 6.42 -> 5.94 ms)
+    //   the stride-2 tile (even / odd columns in separate planes): no (conflicts 0.47 -> 0.15, and 2.295 -> 2.354 ms: r05a_stride2_qpl_pmc.txt)
+    //   the 128-channel stride-1 tiles: no (already conflict-free in the padded layout at a 1536-B pitch; 20.55 -> 20.70 ms)
+    static constexpr bool QPL = STRIDE != 2 && ((MT == 2 && WM == 4) || NT == 1);
     static constexpr int PS = QPL ? 16 : 20;           // floats per patch pixel
     static constexpr int PLANE = STRIDE == 2 ? ((PW + 1) / 2) * 4 : PW * 4;      // QPL: floats per (quad[, parity]) plane of a row
     static constexpr int NP = PH * PW;                 // patch pixels
@@ -250,12 +224,10 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
 {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-#ifndef BSVD_TUNE_SLICE_AUX
-#define BSVD_TUNE_SLICE_AUX 0   // cache policy of the activation (patch slice) loads: 0 default, 2 nt (streamed: every line is read once per tile)
-#endif
+// (cache policy of the activation loads: nt / sc1 nt are slower -- nt also drops the halo rows from the L2; r03)
 __device__ __forceinline__ f32x4 buf_load4_act(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, BSVD_TUNE_SLICE_AUX));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
 struct ChunkSrc {          // wave-uniform description of one 16-channel chunk's source
@@ -278,29 +250,13 @@ struct ChunkSrc {          // wave-uniform description of one 16-channel chunk's
 #ifndef BSVD_TUNE_S2F32_OCC
 #define BSVD_TUNE_S2F32_OCC 2      // waves/SIMD the exact-fp32 stride-2 kernel is compiled for (3 = 168 VGPRs + a 20-B spill: 2.3 % slower)
 #endif
-#ifndef BSVD_TUNE_S2_GROUP
-#define BSVD_TUNE_S2_GROUP 1       // slices per round trip of the split-fp16 stride-2 patch refill
-#endif
-#ifndef BSVD_TUNE_S2_PAIR
-#define BSVD_TUNE_S2_PAIR 2        // refill of the split-fp16 stride-2 tile's single LDS patch buffer (r02 measurements, ms per 10-frame clip for the
-                                   // four stride-2 launches; all variants bit-identical):
-                                   //   0: at every chunk boundary load -> store, row slices or flattened items (BSVD_TUNE_S2_FLAT): 2.36-2.46
-                                   //   1: both 16-channel chunks of a 128-byte line fetched at once, the odd one held in registers: 2.61
-                                   //   2: REGISTER DOUBLE BUFFER -- chunk cb+1 is requested at the boundary before chunk cb and waits in 36 VGPRs
-                                   //      (flattened items: all 256 lanes carry a piece); a boundary is barrier + ds_write + barrier: 2.29 (default)
-                                   //   3: 1 + 2 (line pairs requested one chunk period ahead, 72 VGPRs): 2.49
-                                   // 1 and 3 halve the memory-side line fetches (2.04x -> ~1.1x of the input) and are SLOWER: the re-fetched lines come
-                                   // from the Infinity Cache, the tile lives on occupancy and on not waiting at its boundaries
-#endif
-#ifndef BSVD_TUNE_S2_PAIR_OCC
-#define BSVD_TUNE_S2_PAIR_OCC 2    // waves/SIMD the register-holding variants (BSVD_TUNE_S2_PAIR 1|2) are compiled for
-#endif
-#ifndef BSVD_TUNE_S2_FLAT
-#define BSVD_TUNE_S2_FLAT 9        // split-fp16 stride-2 tile: 16-byte items per lane and round trip of the flattened refill / prologue fill (9 = whole patch; 0: row slices)
-#endif
-#ifndef BSVD_TUNE_FILL
-#define BSVD_TUNE_FILL 1           // 1: the whole LDS patch of a prologue / single-buffer refill in flight at once
-#endif
+// Refill of the split-fp16 stride-2 tile's single LDS patch buffer: a REGISTER DOUBLE BUFFER -- chunk cb + 1 is requested at the boundary before
+// chunk cb and waits in 36 VGPRs (flattened items: all 256 lanes carry a piece); a boundary is barrier + ds_write + barrier: 2.29 ms per clip for
+// the four stride-2 launches.  Measured and removed (knob BSVD_TUNE_S2_PAIR 0 / 1 / 3, all bit-identical): load -> store at every
+// boundary 2.36-2.46; both 16-channel chunks of a 128-byte line fetched at once, the odd one held in registers 2.61 (and requested one chunk period
+// ahead: 2.49) -- these halve the memory-side line fetches (2.04x -> 1.1x of the input) and are SLOWER: the re-fetched half lines come from the
+// Infinity Cache, the tile lives on occupancy and on not waiting at its boundaries.
+constexpr int S2_HOLD_OCC = 2;     // waves/SIMD the register-holding stride-2 tile is compiled for
 #ifndef BSVD_TUNE_FOLD8_OCC
 #define BSVD_TUNE_FOLD8_OCC 3      // waves/SIMD of the split-fp16 fold-8 instantiation (c32-sized networks): 3 = 168 VGPRs + a 20-byte spill in the
                                    // chunk loop's preheader (outside the taps), 2 = no spill
@@ -312,7 +268,7 @@ constexpr int occ_of()
     // exact-fp32 stride 2 (single patch buffer): the refill holds the whole 17x33 patch in registers (72 VGPRs) -> 2 waves/SIMD
     if (C::STRIDE == 2 && PREC == 0 && C::OCC > BSVD_TUNE_S2F32_OCC) return BSVD_TUNE_S2F32_OCC;
     // split-fp16 single-buffer tile with the odd chunk of every 128-byte line held in registers (72 VGPRs): 2 waves/SIMD
-    if (!C::DBUF && PREC == 1 && BSVD_TUNE_S2_PAIR && C::OCC > BSVD_TUNE_S2_PAIR_OCC) return BSVD_TUNE_S2_PAIR_OCC;
+    if (!C::DBUF && PREC == 1 && C::OCC > S2_HOLD_OCC) return S2_HOLD_OCC;
     return C::OCC;
 }
 
@@ -363,7 +319,6 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
 
     TL(0);
     if constexpr (PREC == 1) fp16_saturate_on();      // MODE.FP16_OVFL (bsvd_internal.h): every fp16 conversion of the split mode saturates
-    if (BSVD_TUNE_PRIO == 2) __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -578,11 +533,10 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
         // whole patch in flight at once, then published: one HBM latency per tile instead of one per slice
         auto fill_patch = [&](const ChunkSrc &c, float *pb) {
             // G slices in flight at once, then published.  Everything at once where the registers are there (prologue of
-            // the double-buffered tiles, exact-fp32 stride 2 at 2 waves/SIMD); the split-fp16 stride-2 tile stays at 3
-            // waves/SIMD and takes BSVD_TUNE_S2_GROUP slices per round trip.
+            // the double-buffered tiles, exact-fp32 stride 2 at 2 waves/SIMD)
             // (the fold-8 instantiation issues TWO masked loads per item of its mixed chunk: half the slices per round trip, or the
             //  prologue spills 20 bytes of scratch)
-            constexpr int G = (BSVD_TUNE_FILL && (C::DBUF || PREC == 0)) ? (MIX ? (C::NSLICE + 1) / 2 : C::NSLICE) : BSVD_TUNE_S2_GROUP;
+            constexpr int G = (C::DBUF || PREC == 0) ? (MIX ? (C::NSLICE + 1) / 2 : C::NSLICE) : 1;
 #pragma unroll
             for (int g0 = 0; g0 < C::NSLICE; g0 += G) {
                 f32x4 v[G][C::P];
@@ -594,22 +548,12 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
                     if (g0 + sl < C::NSLICE) slice_store(pb, (g0 + sl) * C::ROWS_PER_SLICE, v[sl]);
             }
         };
-        // Single-buffer split tile (stride 2), PAIR mode.  A 128-byte L2 line holds TWO 16-channel chunks of a pixel.  Fetched one
-        // chunk per boundary, the line is gone from the 4 MiB L2 by the time its second half is wanted (96 resident workgroups
-        // per XCD x 561-pixel patches = 6.9 MB of lines in flight): the PMC passes showed 2.04x the input bytes at the memory
-        // side and the 64->128 layer running at 5.1 TB/s, i.e. HBM-bound on re-fetches.  So every even boundary requests both
-        // halves of each line back to back -- the even chunk goes to LDS, the odd one waits in registers (hold, 72 VGPRs) and
-        // is published at the next boundary without touching memory.
-        constexpr bool PAIR = !C::DBUF && PREC == 1 && BSVD_TUNE_S2_PAIR == 1;
-        constexpr bool REGPF = !C::DBUF && PREC == 1 && BSVD_TUNE_S2_PAIR == 2;     // register double buffer: chunk cb+1 in flight during chunk cb
-        // PAIRPF (3): both of the above -- the two chunks of a 128-byte line are requested together, one chunk period before the
-        // first is needed, and wait in registers (2 x 36 VGPRs): every line is fetched once AND no boundary waits for memory
-        constexpr bool PAIRPF = !C::DBUF && PREC == 1 && BSVD_TUNE_S2_PAIR == 3;
-        // PAIR items: the patch flattened to (row, column, 16-byte quad) items, 256 per pass -- the row-slice map above keeps
-        // only 132 of 256 lanes busy on the 33-pixel rows of this tile, which would double the registers the held chunk costs
+        // Single-buffer split tile (stride 2): register double buffer -- chunk cb + 1 in flight during chunk cb (see S2_HOLD_OCC above).
+        constexpr bool REGPF = !C::DBUF && PREC == 1;
+        // items: the patch flattened to (row, column, 16-byte quad) items, 256 per pass -- the row-slice map above keeps only 132 of 256 lanes busy
+        // on the 33-pixel rows of this tile, which would double the registers the held chunk costs
         constexpr int PNITEM = C::PH * C::ROW_ITEMS, PNI = (PNITEM + 255) / 256;
-        [[maybe_unused]] f32x4 hold[(PAIR || REGPF || PAIRPF) ? PNI : 1];
-        [[maybe_unused]] f32x4 hold_even[PAIRPF ? PNI : 1];
+        [[maybe_unused]] f32x4 hold[REGPF ? PNI : 1];
         auto pair_item = [&](int i, unsigned &voff, int &lds_off, bool &in_patch) {
             const int e = tid + 256 * i;
             const int prow = e / C::ROW_ITEMS, rem = e - prow * C::ROW_ITEMS;
@@ -620,57 +564,16 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
             voff = ok ? (unsigned)(gy * p.W + gxx) * ((unsigned)p.Cin * 4u) + pq4 * 16u : BSVD_OOB;
             lds_off = C::lds_off(prow, pc, pq4);
         };
-        auto fill_pair = [&](int cbe, float *pb) {      // stride-2 layers are plain convs: every chunk comes from the frame itself
-            const unsigned so_e = (unsigned)cbe * 64u;
-            const __amdgpu_buffer_rsrc_t rs_o = cbe + 1 < ncb ? rs_cur : make_rsrc(s.cur, 0u);   // no odd partner: zeros, never used
-            f32x4 v[PNI];
-#pragma unroll
-            for (int i = 0; i < PNI; ++i) {
-                unsigned voff; int lo; bool inp;
-                pair_item(i, voff, lo, inp);
-                v[i] = buf_load4(rs_cur, voff, so_e);
-                if constexpr (PAIR) hold[i] = buf_load4(rs_o, voff, so_e + 64u);
-            }
-#pragma unroll
-            for (int i = 0; i < PNI; ++i) {
-                unsigned voff; int lo; bool inp;
-                pair_item(i, voff, lo, inp);
-                if (inp) *reinterpret_cast<f32x4 *>(pb + lo) = v[i];
-            }
-        };
         auto publish_hold = [&](float *pb) {
 #pragma unroll
             for (int i = 0; i < PNI; ++i) {
                 unsigned voff; int lo; bool inp;
                 pair_item(i, voff, lo, inp);
-                if constexpr (PAIR || REGPF || PAIRPF) if (inp) *reinterpret_cast<f32x4 *>(pb + lo) = hold[i];
+                if constexpr (REGPF) if (inp) *reinterpret_cast<f32x4 *>(pb + lo) = hold[i];
             }
         };
-        // Single-buffer refill on the flattened item map (FLAT): all 256 lanes carry a 16-byte piece per load instruction (the
-        // row-slice map keeps 132 of 256 busy on this tile's 33-pixel rows), so the same registers cover the patch in half the
-        // round trips: BSVD_TUNE_S2_FLAT items per lane and round trip (9 items = the whole 17x33 patch).
-        auto publish_even = [&](float *pb) {
-#pragma unroll
-            for (int i = 0; i < PNI; ++i) {
-                unsigned voff; int lo; bool inp;
-                pair_item(i, voff, lo, inp);
-                if constexpr (PAIRPF) if (inp) *reinterpret_cast<f32x4 *>(pb + lo) = hold_even[i];
-            }
-        };
-        auto prefetch_pair = [&](int cbe) {            // PAIRPF: chunks cbe (even) and cbe+1 of every line, back to back
-            const __amdgpu_buffer_rsrc_t re = cbe < ncb ? rs_cur : make_rsrc(s.cur, 0u);
-            const __amdgpu_buffer_rsrc_t ro = cbe + 1 < ncb ? rs_cur : make_rsrc(s.cur, 0u);
-#pragma unroll
-            for (int i = 0; i < PNI; ++i) {
-                unsigned voff; int lo; bool inp;
-                pair_item(i, voff, lo, inp);
-                if constexpr (PAIRPF) {
-                    hold_even[i] = buf_load4(re, voff, (unsigned)cbe * 64u);
-                    hold[i] = buf_load4(ro, voff, (unsigned)cbe * 64u + 64u);
-                }
-            }
-        };
-        constexpr bool FLAT = !C::DBUF && PREC == 1 && !PAIR && !PAIRPF && (REGPF || BSVD_TUNE_S2_FLAT > 0);
+        // the flattened item map: all 256 lanes carry a 16-byte piece per load instruction (9 items = the whole 17 x 33 patch)
+        constexpr bool FLAT = REGPF;
         auto prefetch_hold = [&](int cbn) {            // REGPF: request chunk cbn into registers; it is published at the next boundary
 #pragma unroll
             for (int i = 0; i < PNI; ++i) {
@@ -680,7 +583,7 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
             }
         };
         auto fill_flat = [&](const ChunkSrc &c, float *pb) {
-            constexpr int GI = BSVD_TUNE_S2_FLAT > 0 ? BSVD_TUNE_S2_FLAT : 1;
+            constexpr int GI = 9;
 #pragma unroll
             for (int g0 = 0; g0 < PNI; g0 += GI) {
                 f32x4 v[GI];
@@ -949,34 +852,17 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
                 *reinterpret_cast<u32x4 *>(rawp + e * 16) = o;
             }
         }
-        else if constexpr (PAIRPF) { prefetch_pair(0); publish_even(patch_buf); }
-        else if constexpr (PAIR) fill_pair(0, patch_buf);
         else if constexpr (FLAT) fill_flat(chunk_src(0), patch_buf);
         else fill_patch(chunk_src(0), patch_buf);
         if constexpr (REGPF) prefetch_hold(1);
         __syncthreads();
         TL(1);
-        if (BSVD_TUNE_PRIO == 2) __builtin_amdgcn_s_setprio(0);
-        if (BSVD_TUNE_PRIO == 3) __builtin_amdgcn_s_setprio(2);
 
         [[maybe_unused]] auto refill_single = [&](int cb, const ChunkSrc &cn) {      // single LDS buffer: after the chunk's barrier
             if (cb + 1 < ncb) {        // single buffer: everybody is done reading it -> refill, publish
-                if constexpr (PAIRPF) {
-                    if ((cb + 1) & 1) {
-                        publish_hold(patch_buf);          // the odd chunk that came with chunk cb
-                        prefetch_pair(cb + 2);            // next line pair: one chunk period ahead of its first use
-                    } else {
-                        publish_even(patch_buf);
-                    }
-                } else if constexpr (REGPF) {
+                if constexpr (REGPF) {
                     publish_hold(patch_buf);
                     prefetch_hold(cb + 2);
-                } else if constexpr (PAIR) {
-                    if ((cb + 1) & 1) {
-                        publish_hold(patch_buf);
-                    } else {
-                        fill_pair(cb + 1, patch_buf);
-                    }
                 } else if constexpr (FLAT) {
                     fill_flat(cn, patch_buf);
                 } else {
@@ -1013,15 +899,7 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
                 for (int mt = 0; mt < C::MT; ++mt) l[mt] = *reinterpret_cast<const f32x4 *>(a_ptr(pc, ky, kx, mt, 1));
             };
             auto pass = [&](const f32x4 (&av)[C::MT], const f32x4 (&bv)[C::NT][2], int bpart) {
-                if constexpr (BSVD_TUNE_PASS_ORDER == 1) {      // weight operand held across consecutive MFMAs instead of the pixel operand
-#pragma unroll
-                    for (int nt = 0; nt < C::NT; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < C::MT; ++mt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bv[nt][bpart]),
-                                                                                 __builtin_bit_cast(f16x8, av[mt]), acc[mt][nt], 0, 0, 0);
-                    return;
-                }
+                // pixel-tile major (channel-tile major -- the weight operand held across consecutive MFMAs: 19.52 -> 19.62 ms, r03)
 #pragma unroll
                 for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
@@ -1084,7 +962,7 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
                         __builtin_amdgcn_sched_barrier(0);                                                               \
                     }                                                                                                    \
                     if constexpr (C::DBUF && !FRONT && !(BSVD_ABL & 2))                                                  \
-                        if ((T) >= BSVD_TUNE_D && (T) <= C::NSLICE - 1 + BSVD_TUNE_D) slice_store(pnext, ((T) - BSVD_TUNE_D) * C::ROWS_PER_SLICE, SOLD); \
+                        if ((T) >= BSVD_SLICE_D && (T) <= C::NSLICE - 1 + BSVD_SLICE_D) slice_store(pnext, ((T) - BSVD_SLICE_D) * C::ROWS_PER_SLICE, SOLD); \
                     ++step;                                                                                              \
                 }
                 if constexpr (LITE) {
@@ -1146,7 +1024,7 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
                     if constexpr (C::DBUF && !FRONT) slice_load(cn, tap * C::ROWS_PER_SLICE, SNEW);   /* rows >= PH: zeros */ \
                     mfma32(a, BCUR);                                                                           \
                     if constexpr (C::DBUF && !FRONT)                                                           \
-                        if (tap >= BSVD_TUNE_D && tap <= C::NSLICE - 1 + BSVD_TUNE_D) slice_store(pnext, (tap - BSVD_TUNE_D) * C::ROWS_PER_SLICE, SOLD); \
+                        if (tap >= BSVD_SLICE_D && tap <= C::NSLICE - 1 + BSVD_SLICE_D) slice_store(pnext, (tap - BSVD_SLICE_D) * C::ROWS_PER_SLICE, SOLD); \
                     ++step;                                                                                    \
                 }
                 if constexpr (C::RING == 3) {
@@ -1231,8 +1109,6 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
         if (oy0 + 2 * C::MT * wm >= p.Ho) return;
 #endif
     }
-    if (BSVD_TUNE_PRIO == 1 || BSVD_TUNE_PRIO == 2) __builtin_amdgcn_s_setprio(2);
-    if (BSVD_TUNE_PRIO == 3) __builtin_amdgcn_s_setprio(0);
     // The epilogue's lane-derived values come from a FRESH lane id (v_mbcnt, opaque to the optimiser) instead of the kernel entry's
     // threadIdx: carried through the K loop they cost the 168-register tiles a 12-16 byte scratch spill (r04 kernel_resources).
     int elane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -1530,13 +1406,8 @@ __global__ __launch_bounds__(256, (PREF ? 2 : occ_of<C, PREC, MIXF>())) void con
                     } else if constexpr ((BSVD_ABL & 64) != 0) {   // timing only: stores kept, no split conversion
                         *reinterpret_cast<f32x4 *>(dst) = f32x4{v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4 *>(dst + 8) = f32x4{v[4], v[5], v[6], v[7]};
                     } else {
-#if BSVD_TUNE_NT_STORE
-                    __builtin_nontemporal_store(__builtin_bit_cast(f32x4, hi), reinterpret_cast<f32x4 *>(dst));
-                    __builtin_nontemporal_store(__builtin_bit_cast(f32x4, lo), reinterpret_cast<f32x4 *>(dst + 8));
-#else
                     *reinterpret_cast<f32x4 *>(dst) = __builtin_bit_cast(f32x4, hi);
                     *reinterpret_cast<f32x4 *>(dst + 8) = __builtin_bit_cast(f32x4, lo);
-#endif
                     }
                 } else {
                     float *dst = t.dst;
@@ -1602,13 +1473,12 @@ static int launch_cfg(const ConvParams &pin, hipStream_t stream, char *name = nu
     return (int)hipGetLastError();
 }
 
-// the fused network entry exists for the quad-planar 64-channel tile only: a tuning build without that layout (BSVD_TUNE_QPL bit 2
-// off) must not instantiate it (static_assert in head_pair) -- it reports the missing kernel instead
+// the fused network entry exists for the quad-planar 64-channel tile only (static_assert in head_pair)
 template <class C>
 static int launch_headf(const ConvParams &p, hipStream_t stream, char *name, int name_len)
 {
     if constexpr (C::QPL) return launch_cfg<C, true, 1, false, true>(p, stream, name, name_len);
-    else { set_error("bsvd_conv3x3: this build (BSVD_TUNE_QPL without bit 2) has no fused-entry kernel"); return -18; }
+    else { set_error("bsvd_conv3x3: no fused-entry kernel for this tile"); return -18; }
 }
 
 // the fused pair exists for the quad-planar 32-channel-wave tiles (the 64-channel layers' tile and the exit tile)
@@ -1616,7 +1486,7 @@ template <class C>
 static int launch_pref(const ConvParams &p, hipStream_t stream, char *name, int name_len)
 {
     if constexpr (C::QPL) return launch_cfg<C, true, 1, false, false, true>(p, stream, name, name_len);
-    else { set_error("bsvd_conv3x3: this build (BSVD_TUNE_QPL) has no fused-pair kernel"); return -20; }
+    else { set_error("bsvd_conv3x3: no fused-pair kernel for this tile"); return -20; }
 }
 
 static bool fast_ok(const ConvParams &p, bool honour_force_generic = true)
@@ -1659,55 +1529,40 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
                 set_error("bsvd_conv3x3: BSVD_F16X3 needs fold %% 16 == 0 (or fold 8 with Cout <= 64), got fold %d with Cout %d", p.fold, p.Cout);
             return -17;
         }
-#ifndef BSVD_TUNE_S2_SPLIT
-#define BSVD_TUNE_S2_SPLIT 0       // 0: 8x16-px tile, single patch buffer; 1: 4x16-px tile, double-buffered
-#endif
         if (p.head_w) {                  // fused network entry (validated by the ABI layer): the 64-channel tile with the first conv inside
             if (stride != 1 || p.fold != 0 || p.Cout > 64 || (p.Cin & 31)) { set_error("bsvd_conv3x3: fused entry needs stride 1, fold 0, Cin %% 32 == 0, Cout <= 64"); return -18; }
             return launch_headf<ConvCfg<4, 1, 2, 2, 1, 3>>(p, stream, name, name_len);
         }
         if (p.y_planar_ch > 0) {         // network exit: 256 px x 32 ch tiles, planar fp32 epilogue
             if (stride != 1 || p.fold != 0 || p.Cout > 32) { set_error("bsvd_conv3x3: planar split output needs stride 1, fold 0, Cout <= 32"); return -16; }
+            if (p.pre_w && p.Cin > 64) { set_error("bsvd_conv3x3: fused pair needs Cin = 32 or 64 (two 32-channel pairs of the first conv)"); return -20; }
             if (p.pre_w) return launch_pref<ConvCfg<2, 1, 4, 1, 1, 3>>(p, stream, name, name_len);       // fused pair: out0 -> exit
             return launch_cfg<ConvCfg<2, 1, 4, 1, 1, 3>, true, 1>(p, stream, name, name_len);
         }
         if (p.pre_w) {                   // fused 64-channel pair (validated by the ABI layer): the narrow tile with the first conv inside
-            if (stride != 1 || p.fold != 0 || p.Cout > 64 || (p.Cin & 31)) { set_error("bsvd_conv3x3: fused pair needs stride 1, fold 0, Cin %% 32 == 0, Cout <= 64"); return -20; }
+            if (stride != 1 || p.fold != 0 || p.Cout > 64 || (p.Cin & 31) || p.Cin > 64) { set_error("bsvd_conv3x3: fused pair needs stride 1, fold 0, Cin = 32 or 64, Cout <= 64"); return -20; }
             return launch_pref<ConvCfg<4, 1, 2, 2, 1, 3>>(p, stream, name, name_len);
         }
         if (stride == 2) {
-            if constexpr (BSVD_TUNE_S2_SPLIT == 1) return launch_cfg<ConvCfg<1, 2, 2, 2, 2, 3, true>, true, 1>(p, stream, name, name_len);
-            else if constexpr (BSVD_TUNE_S2_DBUF == 1) return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, true>, true, 1>(p, stream, name, name_len);
-            else return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, false>, true, 1>(p, stream, name, name_len);
+            // 8 x 16-px tile, ONE patch buffer (a double-buffered patch leaves 1-2 workgroups per CU: slower, r01 / r02)
+            return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, false>, true, 1>(p, stream, name, name_len);
         }
         // The fat tiles run one workgroup per CU, so they need a grid of several rounds of 256; small launches
         // (streaming mode: one frame per launch) keep the 64x64 tiles at 3 workgroups per CU.
         const int64_t fat_wide = (int64_t)p.frames * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16) * ((p.Cout + 127) / 128);
         const int fat_min = p.fat_min_wgs > 0 ? p.fat_min_wgs : BSVD_TUNE_FAT_MIN_WGS;      // BsvdConvArgs.fat_min_wgs (0 = the measured default); no hidden state
-#ifndef BSVD_TUNE_THIN_ALT
-#define BSVD_TUNE_THIN_ALT 0       // 1: small grids of the wide layers (single-frame launches) on <4,1,2,2,1> (256 px x 64 ch workgroups, two channel tiles)
-#endif
         if (p.Cout > 64) {
-#ifndef BSVD_TUNE_FAT_SHAPE
-#define BSVD_TUNE_FAT_SHAPE 0      // wave tile of the 256-px x 128-ch workgroup: 0 = 128 px x 64 ch (<4,2,2,2,1>), 1 = 256 px x 32 ch (<8,1,1,4,1>: half the
-                                   // weight bytes per MFMA, twice the pixel-fragment reads)
-#endif
-            if (fat_wide >= fat_min) {
-                if constexpr (BSVD_TUNE_FAT_SHAPE == 1) return launch_cfg<ConvCfg<8, 1, 1, 4, 1, 3>, true, 1>(p, stream, name, name_len);
-                else return launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
-            }
-            if constexpr (BSVD_TUNE_THIN_ALT != 0) return launch_cfg<ConvCfg<4, 1, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
-            else return launch_cfg<ConvCfg<2, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
+            // wave tile of the 256-px x 128-ch workgroup: 128 px x 64 ch (256 px x 32 ch -- half the weight bytes per MFMA, twice the pixel-fragment
+            // reads -- 19.21 -> 19.60 ms, r03); small grids (single-frame launches): 128 px x 128 ch workgroups (256 px x 64 ch: 291 -> 281 frames/s, r03)
+            if (fat_wide >= fat_min) return launch_cfg<ConvCfg<4, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
+            return launch_cfg<ConvCfg<2, 2, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
         }
         if (p.fold == 8) return launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1, true>(p, stream, name, name_len);   // c32-sized nets
-#ifndef BSVD_TUNE_NARROW_ALT
-#define BSVD_TUNE_NARROW_ALT 1     // 1: 128-px x 32-ch wave tiles (<4,1,2,2,1>, 2 waves per SIMD) for the 64-channel layers instead of 64 px x 64 ch at 3 waves
-                                   // per SIMD: half the weight bytes per MFMA (the 64 x 64 tile pulled 4 KB of weights per wave and tap through the
-                                   // L1: ~42 B/clk/CU of its 64), twice the pixel-fragment reads -- a loss with the padded LDS layout (r01: "no gain"),
-                                   // a 7 % gain with the conflict-free quad-planar one (r03: 6.42 -> 5.94 ms per clip on one box)
-#endif
-        if constexpr (BSVD_TUNE_NARROW_ALT != 0) return launch_cfg<ConvCfg<4, 1, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
-        else return launch_cfg<ConvCfg<2, 2, 4, 1, 1, 3>, true, 1>(p, stream, name, name_len);   // (512-px fat tiles were tried: 9.6 vs 6.8 ms)
+        // the 64-channel layers: 128-px x 32-ch wave tiles (<4,1,2,2,1>, 2 waves per SIMD) instead of 64 px x 64 ch at 3 waves per SIMD: half the weight
+        // bytes per MFMA (the 64 x 64 tile pulled 4 KB of weights per wave and tap through the L1: ~42 B/clk/CU of its 64), twice the pixel-fragment
+        // reads -- a loss with the padded LDS layout (r01), a 7 % gain with the conflict-free quad-planar one (r03: 6.42 -> 5.94 ms per clip).
+        // (512-px fat tiles were tried: 9.6 vs 6.8 ms)
+        return launch_cfg<ConvCfg<4, 1, 2, 2, 1, 3>, true, 1>(p, stream, name, name_len);
     }
     // exact fp32.  Cout <= 64 (the 540x960-level layers of bsvd_c64): 256 px x 64 ch tiles; wider layers: 128 px x 128 ch.
     // Stride 2 always takes the 128 x 128 tile with a single patch buffer (its 17x33 input patch is what bounds LDS).

@@ -40,14 +40,6 @@
 #define BSVD_WX_PERSIST_MIN (1 << 20)   // tiles per CU from which F(2,3) launches take the persistent form.  Measured SLOWER: never, by default
 #endif
 #define BSVD_CUS 256       // MI355X: 256 CUs, one 8-wave workgroup of this kernel each (the tile choice of small grids, launch_winox)
-#ifndef BSVD_WX_ILV
-#define BSVD_WX_ILV 0      // 1: the transform of the next chunk is interleaved INTO each wave's own MFMA stream (sched_group_barrier pipeline) instead of
-                           //    running as a separate phase: a wave that streams MFMAs leaves the other wave of its SIMD about one VALU issue per MFMA
-                           //    (measured: phases of the two waves do not overlap, their times add), its own fillers ride in the MFMA's shadow
-#endif
-#ifndef BSVD_WX_ILV_VALU
-#define BSVD_WX_ILV_VALU 2 // VALU instructions per MFMA in the interleave pipeline
-#endif
 #ifndef BSVD_WX_ABL
 #define BSVD_WX_ABL 0      // TIMING-ONLY ablations (results wrong): 1 no transform in the K loop, 2 no MFMA steps, 4 no epilogue finish, 8 no chunk barrier, 16 transform without its global loads (constant operands: also removes operand toggling), 32 transform without its LDS stores, 64 the K loop re-transforms the prologue's raw registers (no activation loads in the loop, realistic operand values)
 #endif
@@ -111,28 +103,20 @@ struct XCfg {
     static constexpr int PRH = TR / 2 + 2;                 // (FOLD) patch rows of a half
     static constexpr int frag_row(int mt, int ky) { return 4 * mt + ky + (FOLD && mt >= 2 ? 2 : 0); }      // patch row of MFMA tile mt's first row, kernel row ky
     static constexpr int NSLOT = PR * 8;
-#ifndef BSVD_WX_PLANE_PAD
-#define BSVD_WX_PLANE_PAD 0     // bytes added to a plane.  NSLOT * 16 is a multiple of 256 B (all 64 banks), so the two quarters an item wave stores at
-                                // once -- adjacent lanes since the item order puts a pixel's quarters side by side -- meet in the same banks: PMC 0.19
-                                // of the LDS-active cycles are conflict cycles.  128 removes them and changes nothing (-0.5 %): as on the direct
-                                // tiles in round 3, LDS conflicts are not what this kernel waits for
-#endif
-    static constexpr int PLANE = NSLOT * 16 + BSVD_WX_PLANE_PAD;      // bytes of one (xi, quarter) plane
+    static constexpr int PLANE = NSLOT * 16;      // bytes of one (xi, quarter) plane.  (A multiple of 256 B, so the two quarters an item wave stores at once meet in
+                                                  // the same banks: PMC 0.19 of the LDS-active cycles are conflict cycles; padding the planes apart removes them and
+                                                  // changes nothing -- LDS conflicts are not what this kernel waits for.  DESIGN 4.1d, removed knob BSVD_WX_PLANE_PAD)
     static constexpr int V_BUF = A * 4 * PLANE;
     static constexpr int NITEM = NSLOT * 4;       // transform items (row, group, 4 channels) per chunk: 576
     static constexpr int BN = NH * NTW * 32;      // output channels per workgroup
     // epilogue exchange: per round the tiles of MTL MFMA tiles x (NH NTW) channel tiles x A positions, 4 KB each.  It aliases the V
     // buffers -- except in the persistent form, where the next tile's first chunk is already transformed when the epilogue runs:
     // there it sits behind them, and holds one MFMA tile per round so that everything fits 160 KB
-#ifndef BSVD_WX_EPI2
-#define BSVD_WX_EPI2 0     // 1 (F(2,3)): the exchange as two half-size buffers, one MFMA tile per round: round r + 1 is published while round r is finished
-#endif
-    static constexpr bool EPI2 = BSVD_WX_EPI2 && M == 2 && !PERSIST;
-    static constexpr int MTL = (PERSIST || EPI2) ? 1 : 2;
+    static constexpr int MTL = PERSIST ? 1 : 2;
     static constexpr int NRND = MT / MTL;
     static constexpr int NBP = MTL * NH * NTW;    // blocks per round
     static constexpr int XCH_ROUND = NBP * A * 4096;
-    static constexpr int XCH_BYTES = XCH_ROUND * (EPI2 ? 2 : 1);
+    static constexpr int XCH_BYTES = XCH_ROUND;
     static constexpr int XCH_OFF = PERSIST ? 2 * V_BUF : 0;
     static constexpr int LDS_BYTES = PERSIST ? 2 * V_BUF + XCH_BYTES : (2 * V_BUF > XCH_BYTES ? 2 * V_BUF : XCH_BYTES);
     static constexpr int NPART = NW / NBP >= 2 ? 2 : 1;          // finishers per block (column ranges)
@@ -321,15 +305,10 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
     //  and cost more than it saved (the reads' lgkmcnt(0) waits sit inside the MFMA steps).  Measured 6-13 % slower than one tile per
     //  workgroup; kept for the record, never selected: BSVD_WX_PERSIST_MIN.)
     auto next_tile = [&]() __attribute__((always_inline)) {
-#ifndef BSVD_WX_PFNEXT
-#define BSVD_WX_PFNEXT 0   // N > 0: the requests behind a tile's last chunk go to the first chunks (and weight slabs) of the tile N places further down this
-                           // XCD's list -- the one the CU's NEXT workgroup will most likely run (32 CUs per XCD) -- and are never consumed: an L2 prefetch
-                           // for that workgroup's prologue (8-9 K cycles of a 68-114 K tile, most of it the first memory round trip)
-#endif
+        // (an L2 prefetch for the CU's next workgroup from here -- the requests behind a tile's last chunk sent to the tile 32 / 64 places
+        //  further down the XCD's list -- is 3.7 % slower: DESIGN 4.1d, removed knob BSVD_WX_PFNEXT)
         if constexpr (PERSIST) {
             return decode_tile(jt + xcd_wgs);
-        } else if constexpr (BSVD_WX_PFNEXT > 0) {
-            return decode_tile(jt + BSVD_WX_PFNEXT);
         } else {              // no next tile: T with zero-size sources (no decoding -- this sits in the K loop's last iterations)
             XTile t = T;
             t.S.cur_bytes = t.S.prev_bytes = t.S.next_bytes = 0u;
@@ -383,27 +362,19 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
     //      and an inactive lane starts from the out-of-range sentinel; only columns are compared.
     MixConst mixk = {1.0f, -1.0f};
     asm volatile("" : "+s"(mixk.one), "+s"(mixk.mone));         // opaque: see dec_pair / split_pair
-#ifndef BSVD_WX_CH512
-#define BSVD_WX_CH512 2    // channels per transform item of the 512-thread workgroups (2: 4-byte loads, two items per lane; 4: 8-byte loads, one)
-#endif
-    constexpr int CH = C::NTHREADS == 512 ? (M == 2 ? BSVD_WX_CH512 : 2) : 4;
+    constexpr int CH = C::NTHREADS == 512 ? 2 : 4;        // channels per transform item (512-thread workgroups: 4-byte loads, two items per lane)
     static_assert(!XF || CH == 2, "fp32 input: the 2-channel items of the 512-thread workgroups");
     constexpr int NDW = CH / 2;                                   // dwords per pixel and part
     struct Raw { unsigned h[A][NDW], l[A][NDW]; };
-#ifndef BSVD_WX_EMAP
-#define BSVD_WX_EMAP 1     // item -> lane order: 1 the two 8-channel quarters of a slot on ADJACENT lanes (8 (4) consecutive lanes read 32 contiguous
-                           // bytes of one pixel: half the lines per load instruction), 0 quarter-major (16 bytes per line and instruction)
-#endif
-#ifndef BSVD_WX_XIN
-#define BSVD_WX_XIN 1      // scalar position offsets for tiles whose patch columns are all inside the image (item_load)
-#endif
+    // item -> lane order: the two 8-channel quarters of a slot on ADJACENT lanes (8 (4) consecutive lanes read 32 contiguous bytes of one pixel:
+    // half the lines per load instruction of the quarter-major order)
     auto item_geom = [](int E, int &row, int &qb, int &g, int &sub) __attribute__((always_inline)) {
         if constexpr (CH == 4) {
             row = E >> 5; sub = (E & 1) * 8;
-            if constexpr (BSVD_WX_EMAP) { g = (E >> 2) & 7; qb = (E >> 1) & 1; } else { qb = (E >> 4) & 1; g = (E >> 1) & 7; }
+            g = (E >> 2) & 7; qb = (E >> 1) & 1;
         } else {
             row = E >> 6; sub = (E & 3) * 4;
-            if constexpr (BSVD_WX_EMAP) { g = (E >> 3) & 7; qb = (E >> 2) & 1; } else { qb = (E >> 5) & 1; g = (E >> 2) & 7; }
+            g = (E >> 3) & 7; qb = (E >> 2) & 1;
         }
     };
     auto item_load = [&](const XChunkSrc &c, int E, bool active, Raw &r) __attribute__((always_inline)) {
@@ -418,7 +389,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
         if constexpr (XF) {
             // fp32 channels: the item's two channels 8 qb + sub / 2, + 1 are 8 contiguous bytes (8 adjacent lanes = one pixel's 64-byte chunk)
             const unsigned base = active ? (unsigned)((c.oy0 - 1 + row) * p.W + gx0) * c.ps4 + (unsigned)(qb * 32 + 2 * sub) : BSVD_WX_OOB;
-            if (BSVD_WX_XIN && c.x_inside) {            // interior tile: scalar position offsets (see below)
+            if (c.x_inside) {            // interior tile: scalar position offsets (see below)
 #pragma unroll
                 for (int i = 0; i < A; ++i) {
                     const u32x2 v = buf_load2(c.rs, base, c.soff + (unsigned)i * c.ps4);
@@ -434,7 +405,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
             return;
         }
         const unsigned base = active ? (unsigned)((c.oy0 - 1 + row) * p.W + gx0) * c.ps4 + (unsigned)(qb * 16 + sub) : BSVD_WX_OOB;
-        if (BSVD_WX_XIN && c.x_inside) {
+        if (c.x_inside) {
             // every column of the patch is inside the image (all tiles but the first and last of a tile row): the A positions differ by a
             // SCALAR offset -- one address register per item, no compare / select per position (3 VALU each; with the compares the address
             // arithmetic was a fifth of the transform's instructions).  Rows still need nothing: the range check is on the vector offset.
@@ -471,16 +442,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
         item_geom(E, row, qb, g, sub);
         unsigned char *dst = vbuf + qb * C::PLANE + (row * 8 + g) * 16 + sub;
         if constexpr (XF) {
-#ifndef BSVD_WX_XF_PK
-#define BSVD_WX_XF_PK 0     // fp32 input: 1 = BT on channel pairs (v_pk_add_f32 / v_pk_fma_f32): measured 5-7 % SLOWER per layer than channel by channel (r05e: packed fp32 beside MFMA waves), 0 = channel by channel
-#endif
-#if BSVD_WX_XF_PK
-            typedef float f32x2_t __attribute__((ext_vector_type(2)));
-            f32x2_t d[A], v[A];
-#pragma unroll
-            for (int i = 0; i < A; ++i) d[i] = f32x2_t{__builtin_bit_cast(float, r.h[i][0]), __builtin_bit_cast(float, r.l[i][0])};
-            F::input(d, v);                            // BT on the channel pair
-#else
+            // channel by channel (BT on channel PAIRS, v_pk_add_f32: 5-7 % slower per layer -- packed fp32 beside MFMA waves, r05e)
             float d0[A], d1[A], v0[A], v1[A];
             float v[A][2];
 #pragma unroll
@@ -489,7 +451,6 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
             F::input(d1, v1);
 #pragma unroll
             for (int i = 0; i < A; ++i) { v[i][0] = v0[i]; v[i][1] = v1[i]; }
-#endif
 #pragma unroll
             for (int i = 0; i < A; ++i) {
                 unsigned hp, lp;
@@ -507,10 +468,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
                 float d[A];
-#ifndef BSVD_WX_CHBAR
-#define BSVD_WX_CHBAR 1    // scheduling fence per channel of an item (0: the scheduler may interleave an item's channels: more ILP, more live floats)
-#endif
-                if constexpr (BSVD_WX_ILV != 1 && (BSVD_WX_CHBAR || M != 2)) __builtin_amdgcn_sched_barrier(0);    // one channel at a time (the scheduler otherwise decodes everything first: 64 live floats at M = 6)
+                __builtin_amdgcn_sched_barrier(0);    // one channel at a time (the scheduler otherwise decodes everything first: 64 live floats at M = 6)
 #pragma unroll
                 for (int i = 0; i < A; ++i) d[i] = cc ? dec_pair<1>(r.h[i][cp], r.l[i][cp], mixk) : dec_pair<0>(r.h[i][cp], r.l[i][cp], mixk);
                 F::input(d, v[cc]);
@@ -526,61 +484,19 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
             }
         }
     };
-    // The same work in 4 NDW stages with the transformed values carried between them (ILV = 2: a stage per MFMA step):
-    //   stage 4 cp + 0 | 1: decode + BT of channel 2 cp + 0 | 1;  stage 4 cp + 2 | 3: re-split + LDS stores of positions [0, A/2) | [A/2, A)
-    struct Mid { float v[2][A]; };
-    auto item_stage = [&](unsigned char *vbuf, int E, bool active, const Raw &r, Mid &m, auto st_) __attribute__((always_inline)) {
-        constexpr int ST = decltype(st_)::value, cp = ST / 4, q = ST % 4;
-        if constexpr (q < 2) {
-            float d[A];
-#pragma unroll
-            for (int i = 0; i < A; ++i) d[i] = q ? dec_pair<1>(r.h[i][cp], r.l[i][cp], mixk) : dec_pair<0>(r.h[i][cp], r.l[i][cp], mixk);
-            F::input(d, m.v[q]);
-        } else {
-            int row, qb, g, sub;
-            item_geom(E, row, qb, g, sub);
-            unsigned char *dst = vbuf + qb * C::PLANE + (row * 8 + g) * 16 + sub;
-#pragma unroll
-            for (int i = (q - 2) * (A / 2); i < (q - 1) * (A / 2); ++i) {
-                unsigned hp, lp;
-                split_pair(m.v[0][i], m.v[1][i], hp, lp, mixk);
-                if (active) {
-                    *reinterpret_cast<unsigned *>(dst + i * 4 * C::PLANE + cp * 4) = hp;
-                    *reinterpret_cast<unsigned *>(dst + i * 4 * C::PLANE + 2 * C::PLANE + cp * 4) = lp;
-                }
-            }
-        }
-    };
     // A wave's items of chunk `cc` (live index).  768 threads: one 4-channel item on 48 lanes of every wave (576 items).  512 threads:
     // two 2-channel items per lane (1024 of 1152) + 128 left over (rows 16, 17), one more item for the two waves cc % NW, (cc + 1) % NW.
     // 256 threads: two 4-channel items per lane (512 of 576) + 64 left over, one more item for the wave cc % NW.
-    // BAL (the interleaved schedule): no rotating waves -- the left-over items are dealt 16 lanes to every wave as a third, partial item
-    // (a quarter of its lanes active: more instructions per wave, but every wave the same, and all of it in the MFMAs' shadow; a rotating
-    // wave's extra item held the chunk barrier up for ~2000 cycles of 7900)
     // The half-height tile (10 patch rows): one full item per lane instead of two, the same left-over blocks (rows 8, 9).
-    // ILV3: the transform of the NEXT chunk goes into each wave's OWN MFMA stream, one or two instructions behind every MFMA, every micro-step
-    // pinned with scheduling fences (BSVD_WX_ILV = 3; F(2,3), plain-fp32 input, 512-thread workgroups).  Background: r04's microbenchmark and
-    // timeline -- a wave's VALU beside ANOTHER wave's MFMAs on the same SIMD interferes destructively (an MFMA wave beside a VALU wave: 3x
-    // the serial time; in the kernel the second wave's MFMA steps run at 35 % rate while the first one transforms), while VALU behind a wave's
-    // own MFMAs costs about its issue slot (8 x (MFMA + 2 VALU): 592 against 512 cycles).
-    constexpr bool ILV3 = BSVD_WX_ILV == 3 && XF && M == 2 && C::MT == 4 && C::NTHREADS == 512 && CH == 2 && !PERSIST;
-    constexpr bool BAL = (BSVD_WX_ILV == 2 && C::NTHREADS != 768) || ILV3;
-#ifndef BSVD_WX_DEADROWS
-#define BSVD_WX_DEADROWS 0     // 1: a tile with <= 8 image rows (the last tile row of a 135- or 120-row layer) runs its two upper MFMA tiles only: half the MFMA
-                               // steps, the transform of patch rows 0 .. 9 only, one epilogue round; bit-identical.  Measured: 256 -> 256 at 135 rows -1.7 %,
-                               // 256 -> 512 =, and 128 -> 128 at 270 rows (no such tile) +1.7 % -- the six wave-uniform branches split the MFMA steps'
-                               // scheduling regions for every tile.  Net zero on the clip: off
-#endif
-    constexpr bool DEADROWS = BSVD_WX_DEADROWS && M == 2 && C::MT == 4 && !PERSIST && !C::FOLD && BSVD_WX_ILV == 0;    // (F(6,3): 25 spills with it)
-    bool half_live = false;        // wave uniform, set per tile
-    // first patch row of main item sweep k of this wave (a wave's 64 items of a sweep are one row, or two with 4-channel items)
-    auto sweep_dead = [&](int k) __attribute__((always_inline)) { return half_live && ((k * C::NTHREADS + wid * 64) >> (CH == 4 ? 5 : 6)) > 9; };
+    // (Measured and removed, DESIGN 4.1d / 11 with the commit that last held them: the transform inside each wave's own MFMA stream in three forms --
+    //  scheduler-driven, a stage per MFMA step, instruction by instruction: = / +4 % / +8.5 % --, skipping the dead MFMA tiles of a short last row band
+    //  inside the K loop (net zero; the folded / 8-row tail bands below do it per workgroup), uneven dealing of the transform items (slower).)
     constexpr int NITEMS = C::PR * (CH == 4 ? 32 : 64);
     constexpr int NFULL = NITEMS / C::NTHREADS;                                               // whole-workgroup item sweeps per chunk
     constexpr int REM = NITEMS - NFULL * C::NTHREADS;
     constexpr bool PARTIAL = C::NTHREADS != 768 && (REM % 64 != 0 || NFULL == 0);             // the rest as one more sweep with the lanes beyond it idle
-    constexpr int NMAIN = C::NTHREADS == 768 ? 1 : (BAL || PARTIAL) ? NFULL + 1 : NFULL;
-    constexpr int NROT = (C::NTHREADS == 768 || BAL || PARTIAL) ? 0 : REM / 64;               // 64-item blocks left over per chunk
+    constexpr int NMAIN = C::NTHREADS == 768 ? 1 : PARTIAL ? NFULL + 1 : NFULL;
+    constexpr int NROT = (C::NTHREADS == 768 || PARTIAL) ? 0 : REM / 64;               // 64-item blocks left over per chunk
     constexpr int ROT0 = NFULL * C::NTHREADS;                                                 // first left-over item
     static_assert(C::NTHREADS == 768 || C::NTHREADS == 512 || C::NTHREADS == 256, "item map");
     auto lane_id = [&]() __attribute__((always_inline)) {      // opaque per use: the item geometry is re-derived per chunk -- hoisted out of the K loop it pins ~30 registers
@@ -596,49 +512,16 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
     };
     int rot_base = 0;          // chunks of the workgroup's earlier tiles: the rotation runs on across tiles (a chunk is requested under one tile's
                                // numbering and finished under the next one's)
-#ifndef BSVD_WX_ROTA
-#define BSVD_WX_ROTA 0     // how a chunk's transform items are dealt to the 8 waves of the F(2,3) / F(6,3) workgroups (bit-identical results):
-                           //   0  evenly: two 64-item blocks per wave + the two left-over blocks rotating over all eight waves
-                           //   1  the left-over blocks rotate over the four MFMA-FIRST waves only (waves 0-3)
-                           //   2  three blocks per MFMA-first wave, one per transform-first wave + the two left-over blocks rotating over those
-                           // Why: the waves that transform FIRST are the chunk's critical path (timeline r04b: transform 1881 + MFMA steps 4222 cycles
-                           // against 3393 + 1698 for the MFMA-first waves, which then wait 1300 cycles at the chunk barrier)
-#endif
+    // the left-over blocks rotate over all waves (dealt to the MFMA-first waves only, or a whole block more per MFMA-first wave: slower, r05h)
     auto rot_slot = [&](int cc) __attribute__((always_inline)) {                // 0 / 1: this wave takes left-over block 0 / 1 of chunk cc, -1: none
         if constexpr (NROT == 0) return -1;
-        if constexpr (BSVD_WX_ROTA == 1 && C::NW == 8) {
-            if (wid >= 4) return -1;
-            const int d4 = (wid - (cc + rot_base) % 4 + 4) % 4;
-            return d4 < NROT ? d4 : -1;
-        }
         const int d = (wid - (cc + rot_base) % C::NW + C::NW) % C::NW;
         return d < NROT ? d : -1;
     };
-    // ROTA == 2: block map.  NB = NITEMS / 64 blocks of 64 items (18 on the full tile, 10 on the 8-row tile); MFMA-first wave w (0..3) takes
-    // blocks w, 4 + w, (8 + w); transform-first wave w (4..7) takes block 4 KA + w - 4 (full tile only) and, when the rotation picks it, one of
-    // the last two.  Slot k of a wave's raw register sets: k < KA for the first group; k = 0 fixed (full tile) and the next slot rotating for the second.
-    constexpr bool ROTA2 = BSVD_WX_ROTA == 2 && C::NTHREADS == 512 && CH == 2 && !PERSIST && !DEADROWS && NROT == 2;
-    constexpr int KA = C::MT == 4 ? 3 : 2, KBF = C::MT == 4 ? 1 : 0;
-    auto rota_block = [&](int cc, int k) __attribute__((always_inline)) {       // block of slot k for this wave in chunk cc, -1: none (wave uniform)
-        if (wid < 4) return k < KA ? k * 4 + wid : -1;
-        if (k < KBF) return 4 * KA + (wid - 4);
-        if (k == KBF) {
-            const int d4 = ((wid - 4) - (cc + rot_base) % 4 + 4) % 4;
-            return d4 < 2 ? 4 * KA + 4 * KBF + d4 : -1;
-        }
-        return -1;
-    };
     // PP raw register sets: chunk cc's items live in set cc % PP.  PP = 2 where the registers are there (F(2,3)): an item is then
     // requested TWO chunks before it is finished
-#ifndef BSVD_WX_PP_PERSIST
-#define BSVD_WX_PP_PERSIST 1   // raw register sets of the persistent form
-#endif
-#ifndef BSVD_WX_PP
-#define BSVD_WX_PP 2       // raw register sets of F(2,3)'s 512-thread workgroups
-#endif
-    constexpr int PP = (M == 2 && C::NTHREADS == 512 && BSVD_WX_ILV != 2) ? (PERSIST ? BSVD_WX_PP_PERSIST : BSVD_WX_PP) : 1;
-    static_assert(!ROTA2 || (KA <= 3 && NITEMS == (4 * KA + 4 * KBF + 2) * 64), "ROTA 2: block count");
-    constexpr int NSLOTS = ROTA2 ? KA : NMAIN;
+    constexpr int PP = (M == 2 && C::NTHREADS == 512) ? (PERSIST ? 1 : 2) : 1;
+    constexpr int NSLOTS = NMAIN;
     Raw raw[PP][NSLOTS], raw_rot[PP];
     using PAll = std::integral_constant<int, 3>;     // part_: 1 the lanes' main items, 2 the rotating left-over block, 3 both
     auto chunk_load = [&](int cc, int SET, auto part_, int tl) __attribute__((always_inline)) {
@@ -646,44 +529,23 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
         XChunkSrc c;
         if (cc >= T.S.ncb) c = x_chunk_src(next_tile(), cc - T.S.ncb);
         else c = x_chunk_src(T, cc);
-        if constexpr (ROTA2) {
-#pragma unroll
-            for (int k = 0; k < NSLOTS; ++k) {
-                const int blk = rota_block(cc, k);
-                if (blk >= 0) item_load(c, blk * 64 + tl, true, raw[SET][k]);
-            }
-            return;
-        }
         if constexpr (decltype(part_)::value & 1) {
 #pragma unroll
-        for (int k = 0; k < NMAIN; ++k) if (!sweep_dead(k)) item_load(c, main_E(k, tl), main_active(k, tl), raw[SET][k]);
+        for (int k = 0; k < NMAIN; ++k) item_load(c, main_E(k, tl), main_active(k, tl), raw[SET][k]);
         }
         if constexpr (NROT > 0 && (decltype(part_)::value & 2)) {
             const int rs = rot_slot(cc);
-#ifndef BSVD_WX_UNCOND
-#define BSVD_WX_UNCOND 0       // 1: every wave issues the SAME number of activation requests per chunk on every path (a wave without a left-over block: 2 A
-                               // requests from the out-of-range sentinel; behind the last chunk: from zero-size descriptors): see BSVD_WX_LOADLAST (slower)
-#endif
-            if constexpr (BSVD_WX_UNCOND && !DEADROWS) item_load(c, ROT0 + (rs >= 0 ? rs : 0) * 64 + tl, rs >= 0, raw_rot[SET]);
-            else if (rs >= 0 && !half_live) item_load(c, ROT0 + rs * 64 + tl, true, raw_rot[SET]);        // (left-over blocks: patch rows 16, 17)
+            if (rs >= 0) item_load(c, ROT0 + rs * 64 + tl, true, raw_rot[SET]);        // (left-over blocks: patch rows 16, 17)
         }
     };
     auto chunk_finish = [&](int cc, unsigned char *vbuf, int SET, auto part_, int tl) __attribute__((always_inline)) {
-        if constexpr (ROTA2) {
-#pragma unroll
-            for (int k = 0; k < NSLOTS; ++k) {
-                const int blk = rota_block(cc, k);
-                if (blk >= 0) item_finish(vbuf, blk * 64 + tl, true, raw[SET][k]);
-            }
-            return;
-        }
         if constexpr (decltype(part_)::value & 1) {
 #pragma unroll
-        for (int k = 0; k < NMAIN; ++k) if (!sweep_dead(k)) item_finish(vbuf, main_E(k, tl), main_active(k, tl), raw[SET][k]);
+        for (int k = 0; k < NMAIN; ++k) item_finish(vbuf, main_E(k, tl), main_active(k, tl), raw[SET][k]);
         }
         if constexpr (NROT > 0 && (decltype(part_)::value & 2)) {
             const int rs = rot_slot(cc);
-            if (rs >= 0 && !half_live) item_finish(vbuf, ROT0 + rs * 64 + tl, true, raw_rot[SET]);
+            if (rs >= 0) item_finish(vbuf, ROT0 + rs * 64 + tl, true, raw_rot[SET]);
         }
     };
 
@@ -700,24 +562,15 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
     __syncthreads();
 
     const unsigned a_lane = (unsigned)(xi * 4 * C::PLANE + lh * C::PLANE + li * 16);
-#ifndef BSVD_WX_SPRIO
-#define BSVD_WX_SPRIO 0    // wave priority in the K loop (MI355X_MICROARCH "two waves per SIMD": VALU issue is arbitrated by priority, then age):
-                           //   1 / 2: the second- / first-dispatched half of the workgroup at s_setprio 1 for the whole loop;  3: every wave's MFMA steps at 1
-#endif
-    if constexpr (BSVD_WX_SPRIO == 1) { if (wid >= C::NW / 2) __builtin_amdgcn_s_setprio(1); }
-    if constexpr (BSVD_WX_SPRIO == 2) { if (wid < C::NW / 2) __builtin_amdgcn_s_setprio(1); }
-#ifndef BSVD_WX_PHASE
-#define BSVD_WX_PHASE 0    // which waves run the chunk's phases in opposite order: 0 (wid >> 2), 1 wid, 2 (wid >> 1)   (A/B: who shares a SIMD?)
-#endif
-    const int phase = BSVD_WX_PHASE == 3 ? 1 : BSVD_WX_PHASE == 4 ? 0 :       // 3 / 4: every wave transform-first / MFMA-first (the SIMD's waves in step)
-                      C::NW == 4 ? (wid >> 1) : (BSVD_WX_PHASE == 0 ? (wid >> 2) : BSVD_WX_PHASE == 1 ? wid : (wid >> 1)) % C::NPH;
+    // the waves that share a SIMD (w, w + 4, ..) run the chunk's phases in opposite order.  (Other pairings, both waves in step: +5 .. +7 %;
+    //  static wave priorities: 0 .. -6 % -- DESIGN 4.1d, removed knobs BSVD_WX_PHASE / BSVD_WX_SPRIO)
+    const int phase = C::NW == 4 ? (wid >> 1) : (wid >> 2) % C::NPH;
     // (the loop body is written out in the loop, not as a lambda: one more level of by-reference closure nesting and hipcc no longer
     //  promotes the captured locals -- kernel parameters, pointers, the raw sets -- out of private memory)
     [[maybe_unused]] const unsigned long long tl_loop = WXT_NOW();
     [[maybe_unused]] unsigned long long tl_epi = 0;
     for (;;) {                 // the workgroup's tiles: one, or (PERSIST) its share of the XCD's range
     const int ncb = T.S.ncb, oy0 = T.oy0, ox0 = T.ox0, n0 = T.n0, f = T.f;
-    half_live = DEADROWS && p.Ho - oy0 <= 8;
 #pragma unroll
     for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
@@ -749,9 +602,6 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
                     }
                     const f32x4 (&a)[2] = afr[S_ & 1];
                     __builtin_amdgcn_sched_barrier(0);
-                    // (ONE copy of the steps with the lower bands' MFMAs under a wave-uniform condition: two copies of the phase, 6 and 12 steps,
-                    //  made the allocator carry the accumulators twice and spill 840 registers)
-                    if (!(DEADROWS && mt >= 2 && half_live)) {
 #pragma unroll
                     for (int pass = 0; pass < 3; ++pass)
 #pragma unroll
@@ -761,7 +611,6 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
                             const f16x8 av = __builtin_bit_cast(f16x8, a[pass == 0 ? 1 : 0]);
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv, av, acc[mt][nt], 0, 0, 0);
                         }
-                    }
                 }
             });
             // the weights of the NEXT chunk, all three slabs, requested here: a wave's loads return in issue order, so every load a
@@ -770,232 +619,29 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
             static_for<0, 3>([&](auto k_) __attribute__((always_inline)) { load_b((cb + 1) * 3 + decltype(k_)::value, bring[decltype(k_)::value]); });
         };
         // transform step of this iteration: finish chunk cb + 1 (requested PP iterations ago) into the other buffer, request chunk cb + 1 + PP
-#ifndef BSVD_WX_TAILSKIP
-#define BSVD_WX_TAILSKIP 1
-#endif
-#ifndef BSVD_WX_PRIO
-#define BSVD_WX_PRIO 0     // s_setprio level of the transform phase (the MFMA steps run at 0): a wave streaming MFMAs wins the VALU arbitration every cycle
-#endif
-#ifndef BSVD_WX_LOADLAST
-#define BSVD_WX_LOADLAST 0     // 1: the activation requests of an iteration go out BEHIND the MFMA steps in both phase orders (only the finishing moves
-                               // in front of them for the second phase).  Background: hipcc's vmcnt in front of the first MFMA of a phase is vmcnt(11) --
-                               // it drains every activation request the wave has in flight, because the branches around the requests (interior / edge
-                               // tile, left-over block or not) make its counts conservative.  With this, BSVD_WX_UNCOND and BSVD_WX_XIN=0 the counts
-                               // come out exact (vmcnt(35): 24 requests stay in flight) -- and the kernel is 8-10 % SLOWER: the drain is not what a
-                               // wave waits for (the other wave of the SIMD runs meanwhile), early requests are what counts
-#endif
+        // (hipcc's vmcnt in front of the first MFMA of a phase drains every activation request the wave has in flight -- the branches around the
+        //  requests make its counts conservative.  With exact counts, requests behind the MFMA steps in both phase orders, the kernel is 8-10 %
+        //  SLOWER: the drain is not what a wave waits for, early requests are what counts.  DESIGN 4.1d, removed knobs BSVD_WX_LOADLAST / _UNCOND)
         auto xform = [&](auto part_) __attribute__((always_inline)) {      // part_: 1 finish, 2 request, 3 both
             constexpr int XP = decltype(part_)::value;
-            if (BSVD_WX_PRIO) __builtin_amdgcn_s_setprio(BSVD_WX_PRIO);
             const int tl = lane_id();
             // (one tile per workgroup: nothing behind the tile's last chunk -- its transform and the requests of the last PP + 1 iterations
             //  would be zeros from zero-size descriptors, a whole transform phase per tile for nothing)
-            constexpr bool TS_FIN = BSVD_WX_TAILSKIP && !PERSIST, TS_LD = TS_FIN && M == 2 && !BSVD_WX_UNCOND && !(BSVD_WX_PFNEXT > 0);      // (F(6,3) with the request skip too: 25 spills)
+            constexpr bool TS_FIN = !PERSIST, TS_LD = TS_FIN && M == 2;      // (F(6,3) with the request skip too: 25 spills)
             if constexpr (XP & 1) if (!TS_FIN || cb + 1 < ncb) chunk_finish(cb + 1, pnext, setv, PAll{}, tl);
             if constexpr (XP & 2) if (!(BSVD_WX_ABL & 64) && (!TS_LD || cb + 1 + PP < ncb)) chunk_load(cb + 1 + PP, setv, PAll{}, tl);
-            if (BSVD_WX_PRIO) __builtin_amdgcn_s_setprio(0);
         };
         // (one copy of the MFMA steps between two conditional transforms: an if / else with the phases in opposite orders made the
         //  register allocator carry the accumulators in two register sets and spill 60-260 registers)
-        if constexpr (ILV3) {
-            static_assert(NMAIN == 3 && NROT == 0 && NDW == 1 && A == 4 && NTW == 2, "fine interleave: three items per lane, 72 MFMAs per chunk");
-            const int tl = lane_id();
-            // chunk cb + 1 + PP (behind the tile's last chunk: zero-size descriptors -- the micro-steps run unconditionally, no branch in the stream;
-            // what they transform behind the last chunk is zeros into a buffer nobody reads)
-            XChunkSrc cl;
-            if (cb + 1 + PP >= ncb) cl = x_chunk_src(next_tile(), cb + 1 + PP - ncb);
-            else cl = x_chunk_src(T, cb + 1 + PP);
-            // in-flight state of the ONE item being worked on
-            float bt0[A], bt1[A];
-            unsigned hp = 0, lp = 0, lbase = 0;
-            int lgx0 = 0;
-            unsigned char *dst = nullptr;
-            unsigned char *const dummy = xsm + 2 * C::V_BUF + (tl & 15) * 4;       // where an inactive lane's stores go (no exec-mask branch)
-            static_assert(2 * C::V_BUF + 16 * C::PLANE <= C::LDS_BYTES, "dummy store area behind the V buffers");
-            // micro-step m of item k: 0 geometry + store address | 1, 2 BT of channel 0, 1 | 3 + 2 i re-split of position i | 4 + 2 i its two stores |
-            //                         11 geometry of the request | 12 + i request of position i (chunk cb + 1 + PP, into the same registers)
-            auto micro = [&](auto k_, auto m_) __attribute__((always_inline)) {
-                constexpr int k = decltype(k_)::value, m = decltype(m_)::value;
-                Raw &r = raw[setv][k];
-                if constexpr (m == 0) {
-                    int row, qb, g, sub;
-                    item_geom(main_E(k, tl), row, qb, g, sub);
-                    unsigned char *d = pnext + qb * C::PLANE + (row * 8 + g) * 16 + sub;
-                    dst = main_active(k, tl) ? d : dummy;
-                } else if constexpr (m == 1 || m == 2) {
-                    float d[A];
-#pragma unroll
-                    for (int i = 0; i < A; ++i) d[i] = __builtin_bit_cast(float, m == 1 ? r.h[i][0] : r.l[i][0]);
-                    if constexpr (m == 1) F::input(d, bt0); else F::input(d, bt1);
-                } else if constexpr (m < 11 && (m & 1)) {
-                    constexpr int i = (m - 3) / 2;
-                    split_pair(bt0[i], bt1[i], hp, lp, mixk);
-                } else if constexpr (m < 11) {
-                    constexpr int i = (m - 4) / 2;
-                    *reinterpret_cast<unsigned *>(dst + i * 4 * C::PLANE) = hp;
-                    *reinterpret_cast<unsigned *>(dst + i * 4 * C::PLANE + 2 * C::PLANE) = lp;
-                } else if constexpr (m == 11) {
-                    int row, qb, g, sub;
-                    item_geom(main_E(k, tl), row, qb, g, sub);
-                    lgx0 = cl.ox0 - 1 + M * g;
-                    if constexpr (C::FOLD) {
-                        const bool up = row >= C::PRH;
-                        row = up ? row - C::PRH : row;
-                        lgx0 = up ? lgx0 + C::TWPX : lgx0;
-                    }
-                    lbase = main_active(k, tl) ? (unsigned)((cl.oy0 - 1 + row) * p.W + lgx0) * cl.ps4 + (unsigned)(qb * 32 + 2 * sub) : BSVD_WX_OOB;
-                } else {
-                    constexpr int i = m - 12;
-                    const u32x2 v = buf_load2(cl.rs, (unsigned)(lgx0 + i) < (unsigned)p.W ? lbase + (unsigned)i * cl.ps4 : BSVD_WX_OOB, cl.soff);
-                    r.h[i][0] = v[0]; r.l[i][0] = v[1];
-                }
-            };
-            f32x4 afr[2][2];
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) afr[0][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE);
-            static_for<0, 3 * C::MT>([&](auto s_) __attribute__((always_inline)) {
-                constexpr int S_ = decltype(s_)::value, KY = S_ / C::MT, mt = S_ % C::MT;
-                const f32x4 (&b)[NTW][2] = bring[KY];
-                if constexpr (S_ < 3 * C::MT - 1) {
-                    constexpr int KY1 = (S_ + 1) / C::MT, mt1 = (S_ + 1) % C::MT;
-#pragma unroll
-                    for (int pt = 0; pt < 2; ++pt)
-                        afr[(S_ + 1) & 1][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE + C::frag_row(mt1, KY1) * 128);
-                }
-                const f32x4 (&a)[2] = afr[S_ & 1];
-                static_for<0, 3 * NTW>([&](auto j_) __attribute__((always_inline)) {
-                    constexpr int J = decltype(j_)::value, pass = J / NTW, nt = J % NTW, Q = S_ * 3 * NTW + J;
-                    __builtin_amdgcn_sched_barrier(0);
-                    {
-                        const f16x8 bv = __builtin_bit_cast(f16x8, b[nt][pass == 1 ? 1 : 0]);
-                        const f16x8 av = __builtin_bit_cast(f16x8, a[pass == 0 ? 1 : 0]);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv, av, acc[mt][nt], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    // two of every three MFMAs carry a micro-step: 48 = 3 items x 16
-                    if constexpr (Q % 3 < 2) {
-                        constexpr int idx = (Q / 3) * 2 + Q % 3;
-                        micro(std::integral_constant<int, idx / 16>{}, std::integral_constant<int, idx % 16>{});
-                    }
-                });
-                if constexpr (mt == C::MT - 1) { __builtin_amdgcn_sched_barrier(0); load_b((cb + 1) * 3 + KY, bring[KY]); }      // this slab's last use was the step above
-            });
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(BSVD_WX_ABL & 8)) __syncthreads();
-            continue;
-        }
-        if constexpr (BSVD_WX_ILV == 2) {
-            // Manual coarse interleave, pinned with scheduling fences: the 12 (ky, mt) steps of 3 NTW MFMAs each, and behind every step one
-            // slot of the wave's OWN transform work.  (A wave streaming MFMAs leaves the other wave of its SIMD about one VALU issue per MFMA
-            // -- phases of different waves do not overlap, their times add; a wave's own fillers issue in its MFMAs' shadow.)
-            //   PP = 2 (items requested two chunks ahead): stage i behind step i, the requests behind steps 8, 9
-            //   PP = 1: two stages behind each of the first steps, the requests right after them -- the longest way to the next chunk
-            // Stage order: the decode + BT stages of every (item, channel pair) first -- an item's raw registers are free after them and
-            // its request for the chunk after goes out in the next slot, a whole iteration before it is decoded --, then the re-split +
-            // store stages.  SPS stages per slot so that everything fits the 12 slots.
-            using PRot = std::integral_constant<int, 2>;
-            constexpr int NU = NDW * NMAIN;                  // (item, channel pair) units: unit = k * NDW + cp
-            constexpr int NST = 4 * NU;
-            constexpr int SPS = (NST + 3 * C::MT - 1) / (3 * C::MT);             // stages per slot
-            static_assert(PP == 1, "the interleaved schedule requests an item one iteration ahead");
-            [[maybe_unused]] const unsigned long long t0 = WXT_NOW();
-            const int tl = lane_id();
-            XChunkSrc cl;
-            if (cb + 2 >= ncb) cl = x_chunk_src(next_tile(), cb + 2 - ncb);
-            else cl = x_chunk_src(T, cb + 2);
-            Mid mid[NU];
-            // the group fragments of step s + 1 are requested in front of step s's MFMAs (two register sets): an LDS round trip per
-            // step was a third of the MFMA steps' time (52 cycles per MFMA instead of 32 with nothing else on the SIMD)
-            f32x4 afr[2][2];
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) afr[0][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE);
-            static_for<0, 3 * C::MT>([&](auto s_) __attribute__((always_inline)) {
-                constexpr int S_ = decltype(s_)::value, KY = S_ / C::MT, mt = S_ % C::MT;
-                __builtin_amdgcn_sched_barrier(0);
-                {
-                    const f32x4 (&b)[NTW][2] = bring[KY];
-                    if constexpr (S_ < 3 * C::MT - 1) {
-                        constexpr int KY1 = (S_ + 1) / C::MT, mt1 = (S_ + 1) % C::MT;
-#pragma unroll
-                        for (int pt = 0; pt < 2; ++pt)
-                            afr[(S_ + 1) & 1][pt] = *reinterpret_cast<const f32x4 *>(pcur + pt * 2 * C::PLANE + C::frag_row(mt1, KY1) * 128);
-                    }
-                    const f32x4 (&a)[2] = afr[S_ & 1];
-#pragma unroll
-                    for (int pass = 0; pass < 3; ++pass)
-#pragma unroll
-                        for (int nt = 0; nt < NTW; ++nt) {
-                            const f16x8 bv = __builtin_bit_cast(f16x8, b[nt][pass == 1 ? 1 : 0]);
-                            const f16x8 av = __builtin_bit_cast(f16x8, a[pass == 0 ? 1 : 0]);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv, av, acc[mt][nt], 0, 0, 0);
-                        }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // the slot behind this step: stage index G = S_ * SPS + j;  G < 2 NU: decode stage G % 2 of unit G / 2;  else split stage
-                static_for<0, SPS>([&](auto j_) __attribute__((always_inline)) {
-                    constexpr int G = S_ * SPS + decltype(j_)::value;
-                    if constexpr (G < 2 * NU) {
-                        constexpr int un = G / 2, k = un / NDW, cp = un % NDW;
-                        item_stage(pnext, main_E(k, tl), main_active(k, tl), raw[setv][k], mid[un], std::integral_constant<int, 4 * cp + G % 2>{});
-                        // last decode stage of item k: its registers take the request for the chunk after next
-                        if constexpr (cp == NDW - 1 && G % 2 == 1) item_load(cl, main_E(k, tl), main_active(k, tl), raw[setv][k]);
-                    } else if constexpr (G < NST) {
-                        constexpr int H = G - 2 * NU, un = H / 2, k = un / NDW, cp = un % NDW;
-                        item_stage(pnext, main_E(k, tl), main_active(k, tl), raw[setv][k], mid[un], std::integral_constant<int, 4 * cp + 2 + H % 2>{});
-                    }
-                });
-                if constexpr (mt == C::MT - 1) load_b((cb + 1) * 3 + KY, bring[KY]);      // this slab's last use was the step above
-            });
-            __builtin_amdgcn_sched_barrier(0);
-            [[maybe_unused]] const unsigned long long t2 = WXT_NOW();
-            chunk_finish(cb + 1, pnext, setv, PRot{}, tl);
-            chunk_load(cb + 1 + PP, setv, PRot{}, tl);
-            [[maybe_unused]] const unsigned long long t3 = WXT_NOW();
-            if (!(BSVD_WX_ABL & 8)) __syncthreads();
-#ifdef BSVD_WX_TL
-            { const unsigned long long t4 = WXT_NOW(); tl_acc[1] += t2 - t0; tl_acc[2] += t3 - t2; tl_acc[3] += t4 - t3; }
-#endif
-            continue;
-        }
-        if constexpr (BSVD_WX_ILV == 1) {
-            using PMain = std::integral_constant<int, 1>;
-            using PRot = std::integral_constant<int, 2>;
-            [[maybe_unused]] const unsigned long long t0 = WXT_NOW();
-            const int tl = lane_id();            // (a volatile asm: a scheduling-region boundary -- once, in front of the region)
-            __builtin_amdgcn_sched_barrier(0);
-            // one scheduling region: MFMA steps + this lane's main items of the next chunk + the requests for the chunk after
-            chunk_finish(cb + 1, pnext, setv, PMain{}, tl);
-            mfma_phase(std::integral_constant<int, C::MT>{});
-            chunk_load(cb + 1 + PP, setv, PMain{}, tl);
-            static_for<0, 3 * C::MT * 3 * NTW>([&](auto) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, BSVD_WX_ILV_VALU, 0);      // VALU
-                __builtin_amdgcn_sched_group_barrier(0x300, 1, 0);                     // one LDS access (fragment read / V store)
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     // one VMEM read
-            });
-            __builtin_amdgcn_sched_barrier(0);
-            [[maybe_unused]] const unsigned long long t2 = WXT_NOW();
-            chunk_finish(cb + 1, pnext, setv, PRot{}, tl);
-            chunk_load(cb + 1 + PP, setv, PRot{}, tl);
-            [[maybe_unused]] const unsigned long long t3 = WXT_NOW();
-            if (!(BSVD_WX_ABL & 8)) __syncthreads();
-#ifdef BSVD_WX_TL
-            { const unsigned long long t4 = WXT_NOW(); tl_acc[1] += t2 - t0; tl_acc[2] += t3 - t2; tl_acc[3] += t4 - t3; }
-#endif
-            continue;
-        }
         [[maybe_unused]] const unsigned long long t0 = WXT_NOW();
-        using XFin = std::integral_constant<int, BSVD_WX_LOADLAST ? 1 : 3>;
+        using XFin = std::integral_constant<int, 3>;
         if (!(BSVD_WX_ABL & 1) && phase != 0) xform(XFin{});
         __builtin_amdgcn_sched_barrier(0);
         [[maybe_unused]] const unsigned long long t1 = WXT_NOW();
-        if constexpr (BSVD_WX_SPRIO == 3) __builtin_amdgcn_s_setprio(1);
         if (!(BSVD_WX_ABL & 2)) mfma_phase(std::integral_constant<int, C::MT>{});
-        if constexpr (BSVD_WX_SPRIO == 3) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         [[maybe_unused]] const unsigned long long t2 = WXT_NOW();
         if (!(BSVD_WX_ABL & 1) && phase == 0) xform(XFin{});
-        if constexpr (BSVD_WX_LOADLAST) if (!(BSVD_WX_ABL & 1)) xform(std::integral_constant<int, 2>{});
         [[maybe_unused]] const unsigned long long t3 = WXT_NOW();
         if (!(BSVD_WX_ABL & 8)) __syncthreads();
 #ifdef BSVD_WX_TL
@@ -1004,7 +650,6 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
     }
     }
 
-    if constexpr (BSVD_WX_SPRIO == 1 || BSVD_WX_SPRIO == 2) __builtin_amdgcn_s_setprio(0);
     tl_epi = WXT_NOW();
     // ---- epilogue: NRND rounds of publish -> finish
     const int Cq = p.Cout >> 2;
@@ -1032,7 +677,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
         // publish: block (mtl, channel tile hh * NTW + nt), position xi: [4 register quads][64 lanes] x 16 B, slot XOR-swizzled
         auto publish = [&](auto rnd_) __attribute__((always_inline)) {
             constexpr int rnd = decltype(rnd_)::value;
-            unsigned char *const xr = xch + (C::EPI2 ? (rnd & 1) * C::XCH_ROUND : 0);
+            unsigned char *const xr = xch;
 #pragma unroll
             for (int mtl = 0; mtl < C::MTL; ++mtl)
 #pragma unroll
@@ -1047,17 +692,10 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
                     }
                 }
         };
-        if constexpr (C::EPI2) { publish(std::integral_constant<int, 0>{}); __syncthreads(); }
         static_for<0, C::NRND>([&](auto rnd_) __attribute__((always_inline)) {
             constexpr int rnd = decltype(rnd_)::value;
-            if (DEADROWS && half_live && C::MTL * rnd >= 2) return;      // (wave uniform, the same for every wave of the workgroup) no image rows in this round's MFMA tiles
-            if constexpr (C::EPI2) {
-                // the other buffer's readers (round rnd - 1) passed the barrier at the end of their round
-                if constexpr (rnd + 1 < C::NRND) publish(std::integral_constant<int, rnd + 1>{});
-            } else {
-                if (rnd) __syncthreads();                // round 0's readers are done
-                publish(rnd_);
-            }
+            if (rnd) __syncthreads();                // round 0's readers are done
+            publish(rnd_);
             // PixelShuffle + skip: the skip values of this round's pixels are requested HERE, in front of the barrier and the exchange reads (asked
             // for at the point of use, each of the 8 requests per wave and tile stood exposed for a DRAM round trip)
             constexpr int JN_ = M / C::NPART;
@@ -1065,10 +703,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
             static_assert(!C::FOLD || 2 % C::MTL == 0, "a round holds MFMA tiles of one half");
             constexpr int FDY = C::FOLD && C::MTL * rnd >= 2 ? -8 : 0, FDX = C::FOLD && C::MTL * rnd >= 2 ? C::TWPX : 0;
             [[maybe_unused]] f32x4 skh[2][JN_], skl[2][JN_];
-#ifndef BSVD_WX_SKIPPF
-#define BSVD_WX_SKIPPF 1
-#endif
-            constexpr bool SKIPPF = BSVD_WX_SKIPPF && M == 2 && !PERSIST;        // (F(4,3) / F(6,3): the 32-48 registers it holds spill)
+            constexpr bool SKIPPF = M == 2 && !PERSIST;        // (F(4,3) / F(6,3): the 32-48 registers it holds spill)
             if constexpr (EPI == BSVD_EPI_PS_ADD && SKIPPF) {
                 if (has_skip && part < C::NPART) {
 #pragma unroll
@@ -1088,8 +723,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
                     }
                 }
             }
-            if constexpr (!C::EPI2) __syncthreads();
-            unsigned char *const xch = xsm + C::XCH_OFF + (C::EPI2 ? (rnd & 1) * C::XCH_ROUND : 0);
+            __syncthreads();
             [&]() __attribute__((always_inline)) {
             // finish
             if (part >= C::NPART || (BSVD_WX_ABL & 4)) return;
@@ -1176,7 +810,6 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
                 }
             }
             }();
-            if constexpr (C::EPI2 && rnd + 1 < C::NRND) __syncthreads();      // this round's readers are done; the next round's tiles are published
         });
     };
     using std::integral_constant;

@@ -37,12 +37,12 @@ def head_fusable(inc0, inc3, precision):
 
 def pair_fusable(a, b, precision):
     """Can two consecutive plain stride-1 convs a -> b run as ONE launch (BsvdConvArgs.pre_w_packed)?  Split-fp16 mode, both without
-    temporal shift, a's (padded) output = b's input in whole 32-channel pairs, b with <= 64 output channels and a PLAIN or RESID
+    temporal shift, a's (padded) output = b's input in ONE or TWO whole 32-channel pairs (the kernel carries two), b with <= 64 output channels and a PLAIN or RESID
     epilogue (the planar exit included).  The 64-channel full-resolution pairs of a DenBlock: OutputCvBlock out0 -> out3 and, where the
     block has no planar entry, InputCvBlock inc0 -> inc3 (bsvd_arch.py:194-226, 287-306)."""
     return (precision == "f16x3" and a.stride == 1 and b.stride == 1 and not a.tsm and not b.tsm and a.epilogue == EPI_PLAIN
             and b.epilogue in (EPI_PLAIN, EPI_RESID) and a.cin_pad % 16 == 0 and a.cin > 4 and a.cout_pad == b.cin_pad
-            and b.cin_pad % 32 == 0 and b.cout_pad <= 64)
+            and b.cin_pad % 32 == 0 and b.cin_pad <= 64 and b.cout_pad <= 64)
 
 
 # Forms of the wide layers: "direct" (3-pass implicit GEMM), "wino2" (1-D Winograd F(2,3) along x; default of arch.BSVD), "wino6" (F(6,3)),
@@ -123,6 +123,13 @@ class PackedNet:
             # layer, the planar-output exit layer included, is split-packed for the MFMA kernel
             edge = {net.layers[0].key}
         with torch.cuda.device(device):
+            # max |w| of every layer the Winograd form could take, in ONE host round trip (a float() per layer is a device sync per layer)
+            cand = [sp for sp in net.layers if self.wino_m and wino_eligible(sp, precision, self.wino_min_cin)]
+            self._wmax = {}
+            if cand:
+                mx = torch.stack([state[sp.key + ".weight"].detach().to(device=device, dtype=torch.float32).abs().max()
+                                  if state[sp.key + ".weight"].numel() else torch.zeros((), device=device) for sp in cand]).cpu()
+                self._wmax = {sp.key: float(v) for sp, v in zip(cand, mx)}
             for sp in net.layers:
                 w = state[sp.key + ".weight"].detach().to(device=device, dtype=torch.float32).contiguous()
                 b = state.get(sp.key + ".bias")
@@ -209,7 +216,7 @@ class PackedNet:
             m = abi = 2
         # fp16 range of the TRANSFORMED weights U = G g: |U| <= max |w| x the form's largest |G| row sum (1.5 for F(2,3), 15 for F(6,3)).
         # A BN-folded layer inside the raw-weight guard (arch.F16X3_WEIGHT_LIMIT) can still leave fp16's range here: it keeps the direct form
-        wmax = float(w.abs().max()) if w.numel() else 0.0
+        wmax = self._wmax[sp.key] if sp.key in self._wmax else (float(w.abs().max()) if w.numel() else 0.0)
         if not wmax * WINO_G_ROW_SUM[m] <= F16_PAIR_LIMIT:
             self.wino_range_fallback.append((sp.key, wmax, m))
             import warnings

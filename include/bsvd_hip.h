@@ -153,7 +153,7 @@ typedef struct BsvdConvArgs {
      * hosts short of bandwidth, not of matrix time.  x is the first
      * conv's NHWC input [frames][H][W][pre_cin] (x_frame_stride its frame stride); pre_w_packed = bsvd_pack_weights(dtype
      * BSVD_F16X3) of the first conv (pre_cin -> Cin), pre_bias its bias_packed [Cin].  Both convs: OutputCvBlock / InputCvBlock,
-     * bsvd_arch.py:194-226, 287-306.  Needs pre_cin % 16 == 0, Cin % 32 == 0, Cout <= 64, stride 1, fold 0, no planar INPUT, no
+     * bsvd_arch.py:194-226, 287-306.  Needs pre_cin % 16 == 0, Cin = 32 or 64 (the kernel carries two 32-channel pairs of t), Cout <= 64, stride 1, fold 0, no planar INPUT, no
      * head_w_packed / w_wino_packed; anything else returns -20 with the reason.  Per output the arithmetic of both convs is the
      * stand-alone kernels': fused == unfused bit for bit. */
     const void *pre_w_packed;

@@ -144,3 +144,28 @@ def test_fused_pair_refuses_what_it_cannot_run():
         setattr(args, field, old)
     assert lib.bsvd_conv3x3(ctypes.byref(args), None) == 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("cm", [96, 128])
+def test_fused_pair_refuses_a_middle_tensor_wider_than_two_channel_pairs(cm):
+    """the kernel carries TWO 32-channel pairs of the first conv's output; with cm = 96 / 128 chunks 4.. of the
+    second conv's K would be refilled with pair 1's data.  The engine does not pair such layers, and the ABI refuses them with -20."""
+    from bsvd_amd import _lib
+    from bsvd_amd.engine import HipExecutor, PackedNet, pair_fusable
+    from bsvd_amd.netspec import ConvSpec
+    a = ConvSpec("out0", "a", 64, cm, 1, False, "relu6", 0)
+    b = ConvSpec("out3", "b", cm, 64, 1, False, "relu6", 0)
+    assert not pair_fusable(a, b, "f16x3")
+    st = seeded_state([("e0.weight", (16, 4, 3, 3)), ("e0.bias", (16,)), ("a.weight", (cm, 64, 3, 3)), ("a.bias", (cm,)),
+                       ("b.weight", (64, cm, 3, 3)), ("b.bias", (64,)), ("e1.weight", (3, 16, 3, 3)), ("e1.bias", (3,))], 5)
+    net = _PairNet(a, b)
+    ex = HipExecutor(PackedNet(net, {k: torch.as_tensor(v) for k, v in st.items()}, torch.device("cuda", 0), "f16x3", "direct", fuse_pairs=True))
+    assert not ex.fuse_pair(net.temp1, "out0", "out3")
+    # the ABI asked explicitly: a valid 64 -> 64 -> 64 request with the middle width raised (validation precedes any launch)
+    a64, b64, _, fused, _ = _setup(64, 64, 64, "relu6", "relu6", 0)
+    xs = to_split(torch.zeros(1, 8, 16, 64)).cuda()
+    args, _ = fused.build_args(b64, xs, pre=a64)
+    args.Cin = cm
+    lib = _lib.load()
+    rc = lib.bsvd_conv3x3(ctypes.byref(args), None)
+    assert rc == -20 and b"Cin = 32 or 64" in lib.bsvd_last_error(), (rc, lib.bsvd_last_error())

@@ -25,7 +25,7 @@ LAYERS = [  # cin, cout, tsm, act, epi, H, W, T
     (256, 256, True, "relu6", 0, 270, 480, 1),
     (128, 256, False, "none", 1, 540, 960, 1),
     (256, 512, False, "none", 1, 270, 480, 1),
-    (64, 64, False, "relu6", 0, 540, 960, 10),      # the 64-channel layers (not Winograd-eligible by default: BSVD_WINO_MIN_CIN=64 to try)
+    (64, 64, False, "relu6", 0, 540, 960, 10),      # the 64-channel layers (not Winograd-eligible by default: PackedNet(wino_min_cin=64) to try)
 ]
 if os.environ.get("WINO_LAYERS"):
     LAYERS = [LAYERS[int(i)] for i in os.environ["WINO_LAYERS"].split(",")]
