@@ -66,6 +66,29 @@ def synth_clip(frames, seed, device, h=None, w=None):
     return lq.to(device), nm.to(device)
 
 
+def synth_window(start, end, block, device, h, w, blind):
+    """frames [start, end) of the clip whose block b (frames [b * block, (b + 1) * block)) is synth_clip(block, 100 + b): [F,C,h,w]"""
+    parts = []
+    for b in range(start // block, (end - 1) // block + 1):
+        lq, nm = synth_clip(block, 100 + b, device, h, w)
+        v = (lq if blind else torch.cat([lq, nm], dim=2))[0]
+        lo, hi = max(start, b * block) - b * block, min(end, (b + 1) * block) - b * block
+        parts.append(v[lo:hi])
+    return torch.cat(parts, dim=0).contiguous() if len(parts) > 1 else parts[0].contiguous()
+
+
+def output_digests(y, first_frame, block=10):
+    """sha256 (16 hex digits) of every whole `block`-frame block of the job's output that lies inside this rank's window [first_frame, ..):
+    {block index: digest}.  Outside every timed region."""
+    import hashlib
+    out = {}
+    n = y.shape[0]
+    for b in range((first_frame + block - 1) // block, (first_frame + n) // block):
+        lo = b * block - first_frame
+        out[b] = hashlib.sha256(y[lo:lo + block].contiguous().cpu().numpy().tobytes()).hexdigest()[:16]
+    return out
+
+
 def build_model(device, precision="fp32", blind=False, wide_conv="auto", fuse_pairs="auto", f32_handover="auto"):
     import bsvd_amd
     torch.manual_seed(1234)      # random-init weights of the bsvd_c64 architecture (no checkpoint in the tree)
@@ -289,7 +312,7 @@ def cpu_baseline(model, h, w, blind, frames=10):
                       "1 warm-up + best of 2; host CPU: %s" % (frames, 3 if blind else 4, h, w, cpu)}
 
 
-def power_probe(step, seconds):
+def power_probe(step, seconds, allow_empty=False):
     """rocm-smi package power / shader clock while `step` loops (untimed, after the timed region, N = 1 only): the split mode runs at
     the package power cap with the clock throttled, and the line should say so itself.  None if rocm-smi is
     absent or prints something else."""
@@ -326,22 +349,98 @@ def power_probe(step, seconds):
     th.start()
     t0 = time.perf_counter()
     nsteps = 0
+    gpu = torch.cuda.is_available()
+    e0, e1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if gpu else (None, None)
     with torch.no_grad():
+        if gpu:
+            e0.record()
         while time.perf_counter() - t0 < seconds:
             for _ in range(4):
                 step()
             nsteps += 4
-            if torch.cuda.is_available():
+            if gpu:
                 torch.cuda.synchronize()
+        if gpu:
+            e1.record()
+            torch.cuda.synchronize()
     loop_s = time.perf_counter() - t0
+    event_ms = e0.elapsed_time(e1) if gpu else None      # HIP events around the whole loop (bench.box_calibration times its layers with them)
     stop.set()
     th.join(timeout=15)
     rows = rows[1:] if len(rows) > 2 else rows                    # the first sample may predate the loop
     if not rows:
-        return None
-    return {"package_w": sum(r[0] for r in rows) / len(rows), "cap_w": float(cap.group(1)) if cap else None,
+        return {"package_w": None, "cap_w": float(cap.group(1)) if cap else None, "sclk_mhz": None, "samples": 0, "loop_steps": nsteps,
+                "loop_seconds": loop_s, "event_ms": event_ms, "source": "no rocm-smi sample landed inside the loop"} if allow_empty else None
+    return {"event_ms": event_ms, "package_w": sum(r[0] for r in rows) / len(rows), "cap_w": float(cap.group(1)) if cap else None,
             "sclk_mhz": sum(r[1] for r in rows) / len(rows), "samples": len(rows), "loop_steps": nsteps, "loop_seconds": loop_s,
             "source": "rocm-smi --showpower --showclocks every ~0.5 s while the same step loops for %.1f s after the timed region" % seconds}
+
+
+# ---- box calibration: two FIXED layers on seeded operands, timed outside the timed region, so that a line says how fast
+# ITS box is next to the box the reference figures below come from.  The driver's boxes differ by +-5 % on the same commit (r05: 366.0 on
+# the driver's box, 384.4 on the builder's); without this, "did round N beat round N-1" had to be inferred from untouched kernels.
+#   direct64 : out0 of DenBlock 1 (64 -> 64 plain conv at 540 x 960, 10 frames), the direct-form MFMA tile <4,1,2,2,1>.  Its device code is
+#              byte-identical since round 5 (ISA digest of conv3x3_mfma.hip unchanged by round 6) -- the NORMALISATION BASIS: the kernel
+#              a round works on must not normalise its own gain away
+#   wino256  : d1c2 of DenBlock 1 (256 -> 256 temporal-fusion conv at 135 x 240, 10 frames) in the shipped form -- informational: what the
+#              round's dominant kernel does on this box
+# Reference figures: a NOMINAL box = the r05 record box (profiles/r06_box_calibration.json lists the boxes seen so far under this protocol).
+BOX_CAL_REF = {"direct64_ms": 1.000, "wino256_ms": 0.631,
+               "source": "nominal reference box = the r05 record box (direct64 0.990 ms in its clip, 256->256 F(2,3) 0.631 ms, C1 384.4 frames/s); the r05 "
+                         "driver box: direct64 1.038, C1 366.0; the r06 session-1 box: 1.047, C1 366.8 (profiles/r06_box_calibration.json)"}
+
+
+def normalise_value(value, cal_ms, ref_ms):
+    """frames/s this run would show on the reference box: a box whose fixed calibration layer takes cal_ms where the reference box takes
+    ref_ms is cal_ms / ref_ms slower, and throughput scales with the inverse.  None when either figure is missing."""
+    if not cal_ms or not ref_ms or cal_ms <= 0 or ref_ms <= 0:
+        return None
+    return value * (cal_ms / ref_ms)
+
+
+def box_calibration(model, x, seconds=0.7):
+    """ms per launch of the two fixed layers (HIP events around a ~`seconds` loop each, after a short ramp), with the clock and package power
+    rocm-smi shows meanwhile.  `x`: the step's own [F,C,H,W] clip -- the 64-channel operand is DenBlock 1's real x0 for its first 10 frames
+    (seeded clip + seeded weights: the same bits on every box); the 256-channel operand is a seeded uniform [0, 6) tensor."""
+    from bsvd_amd import schedule
+    dev = x.device
+    ex = model._executor(dev)
+    S = model.net.temp1
+    out = {}
+    with torch.no_grad():
+        x0 = schedule._inc(ex, S, x[:10].contiguous(), True)
+        g = torch.Generator(device="cpu").manual_seed(77)
+        sp_w = S["d1c2"]
+        h4, w4 = (x.shape[-2] + 3) // 4, (x.shape[-1] + 3) // 4
+        xw = (torch.rand((10, h4, w4, sp_w.cin_pad), generator=g) * 6.0).to(dev)
+        f32_in = sp_w.key in getattr(ex.packed, "f32_in", ())
+        if not f32_in and ex.split:            # a pack without the fp32 hand-over reads fp16 pairs: feed it a real split tensor instead
+            xw = None
+        legs = [("direct64", S["out0"], x0)] + ([("wino256", sp_w, xw)] if xw is not None else [])
+        for name, sp, inp in legs:
+            ex.record_variants = True
+            ex.conv(sp, inp)
+            ex.record_variants = False
+            variant = ex.last_variant
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.15:          # ramp
+                for _ in range(16):
+                    ex.conv(sp, inp)
+                torch.cuda.synchronize()
+            pw = power_probe(lambda: [ex.conv(sp, inp) for _ in range(8)], seconds, allow_empty=True)
+            if pw is None:                                  # no rocm-smi at all: plain event timing
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(256):
+                    ex.conv(sp, inp)
+                e1.record()
+                torch.cuda.synchronize()
+                pw = {"event_ms": e0.elapsed_time(e1), "loop_steps": 32, "sclk_mhz": None, "package_w": None}
+            n = pw["loop_steps"] * 8
+            out[name] = {"ms_per_launch": pw["event_ms"] / n, "launches": n, "sclk_mhz": pw["sclk_mhz"], "package_w": pw["package_w"], "kernel": variant,
+                         "layer": "%s %d->%d, %s, 10 frames" % (sp.name, sp.cin, sp.cout, "x".join(str(d) for d in inp.shape[1:3]))}
+    return out
 
 
 def init_groups(dist, device, rank, world):
@@ -393,6 +492,10 @@ def main():
                     help="tensors only Winograd-form layers read as plain fp32 instead of fp16 pairs (BSVD(f32_handover=...); auto = on)")
     ap.add_argument("--wide-conv", default="auto", help="arithmetic form of the wide split-fp16 layers: auto (= wino2) | direct | wino2 | wino6 | "
                                                         "wino26 (bsvd_amd.engine.WIDE_CONV; the driver's line runs the default)")
+    ap.add_argument("--output-digest", action="store_true",
+                    help="add `output_digest`: sha256 of every 10-frame block of the job's output (all ranks, in frame order) -- N = 1 and N = 8 "
+                         "of --scaling strong run the same clip and must print the same list")
+    ap.add_argument("--no-box-calibration", action="store_true", help="skip the two fixed calibration layers (~2 s) after the timed region")
     ap.add_argument("--no-power-probe", action="store_true", help="skip the 2.5 s rocm-smi power / clock sample after the timed region")
     ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["fp32", "f16x3"],
                     help="fp32: exact fp32 MFMA; f16x3: split-fp16 3-pass MFMA, fp32 accumulate (fp32-class accuracy)")
@@ -439,9 +542,11 @@ def main():
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         halo_group, halo_transport = init_groups(dist, device, rank, world)
 
-    lq, nm = synth_clip(frames, 100 + rank, device, h, w)      # this rank's window of the clip
-    x = (lq if wl["blind"] else torch.cat([lq, nm], dim=2))[0].contiguous()   # [F,C,H,W] resident in HBM before timing
-    del lq, nm
+    # This rank's window of the job's clip.  The clip is defined block by block (seed 100 + block index): weak scaling = one block of
+    # `frames` frames per rank (rank r draws seed 100 + r, as every round's records did); strong scaling = blocks of 10 frames, so that
+    # N = 1 and N = 8 run the SAME 80-frame C4 clip and their output digests can be compared block by block (`output_digest`).
+    block = frames if args.scaling == "weak" else (10 if args.total_frames % 10 == 0 else args.total_frames)
+    x = synth_window(rank * frames, (rank + 1) * frames, block, device, h, w, wl["blind"])      # [F,C,H,W] resident in HBM before timing
 
     def barrier():
         if dist is not None:
@@ -536,6 +641,14 @@ def main():
                 for e in model._stream_engs.values():
                     e.layerwise = False
         assert tuple(y.shape) == (frames, 3, h, w) and (bool(torch.isfinite(y).all()) or os.environ.get("BSVD_ABL_TIMING") == "1")   # (timing-only ablation builds of tools/ab_prebuilt.sh)
+        model.bench_digests = None
+        if args.output_digest:
+            mine_d = output_digests(y, rank * frames)
+            if dist is not None:
+                allg = [None] * world
+                dist.all_gather_object(allg, mine_d)
+                mine_d = {k: v for d_ in allg for k, v in d_.items()}
+            model.bench_digests = [mine_d[k] for k in sorted(mine_d)]
         t_max = torch.tensor([dt], dtype=torch.float64)
         if dist is not None:
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -622,7 +735,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": (wl["name"] % (frames * world)) + ", %s, random-init weights%s"
                                    % (api, "; frame-window sharded with per-layer RCCL halo" if world > 1 else ""),
-                       "baseline_config": args.workload if world == 1 or args.workload != "c1" else "c4" if frames * world == 80 else "c1 x%d" % world,
+                       "baseline_config": ("c4" if frames * world == 80 else args.workload if world == 1 else "c1 x%d" % world) if args.workload == "c1" else args.workload,
                        "frames_per_gpu": frames, "parallelism": "frame-window x%d" % world,
                        "schedule": mode, "halo_transport": halo_transport, "wide_conv": model.wide_conv, "fuse_pairs": model.fuse_pairs,
                        "flop_per_frame": flop_per_frame},
@@ -657,6 +770,21 @@ def main():
             out["sustained"] = {"value": frames * pw["loop_steps"] / pw["loop_seconds"], "unit": "frames/s", "seconds": pw["loop_seconds"],
                                 "sclk_mhz": pw["sclk_mhz"], "package_w": pw["package_w"],
                                 "note": "untimed loop of the same step after the timed region (N = 1); `value` above is the K-step burst"}
+        if world == 1 and not args.no_box_calibration:
+            try:
+                cal = box_calibration(model, x)
+            except Exception as e:                                   # noqa: BLE001 - a measurement aid must never fail the bench
+                cal = {"error": "%s: %s" % (type(e).__name__, e)}
+            cal["reference"] = BOX_CAL_REF
+            d64 = cal.get("direct64", {}).get("ms_per_launch")
+            cal["ratio_direct64"] = (d64 / BOX_CAL_REF["direct64_ms"]) if d64 else None
+            cal["note"] = ("fixed layers on seeded operands, looped ~0.7 s each after the timed region; value_normalised = value x "
+                           "(this box's direct64 ms / the reference box's): the frames/s this commit would show on the reference box")
+            out["box_calibration"] = cal
+            out["value_normalised"] = normalise_value(fps, d64, BOX_CAL_REF["direct64_ms"])
+        if getattr(model, "bench_digests", None):
+            out["output_digest"] = {"sha256_16_per_10_frame_block": model.bench_digests, "blocks": len(model.bench_digests),
+                                    "of": "the last timed step's output, frame order over all ranks"}
         if stream_stats:
             out["stream_engine"] = stream_stats
         if world > 1:

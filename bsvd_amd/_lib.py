@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BSVD_HIP_LIB") or os.path.join(_HERE, "libbsvd_hip.so")   # env override: A/B tuning builds
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 BSVD_F32, BSVD_F16, BSVD_F16X3 = 0, 1, 2
 ACT = {"none": 0, "relu": 1, "relu6": 2}
 EPI_PLAIN, EPI_PS_ADD, EPI_RESID = 0, 1, 2
@@ -19,7 +19,8 @@ EXPORTS = ("bsvd_abi_version", "bsvd_conv_args_size", "bsvd_build_info", "bsvd_l
            "bsvd_packed_head_weight_bytes", "bsvd_pack_head_weights", "bsvd_packed_wino_weight_elems", "bsvd_pack_weights_wino",
            "bsvd_nchw_to_nhwc", "bsvd_nhwc_to_nchw", "bsvd_halo_pack", "bsvd_halo_unpack", "bsvd_workspace_bytes",
            "bsvd_u8_to_planar", "bsvd_planar_to_u8", "bsvd_conv3x3_batch", "bsvd_graph_begin", "bsvd_graph_fork",
-           "bsvd_graph_join", "bsvd_graph_end", "bsvd_graph_abort", "bsvd_graph_launch", "bsvd_graph_destroy")
+           "bsvd_graph_join", "bsvd_graph_end", "bsvd_graph_abort", "bsvd_graph_launch", "bsvd_graph_destroy",
+           "bsvd_v_frame_elems", "bsvd_v_groups", "bsvd_to_v")
 
 
 class BsvdConvArgs(ctypes.Structure):
@@ -58,6 +59,7 @@ class BsvdConvArgs(ctypes.Structure):
         ("pre_bias", ctypes.c_void_p),
         ("pre_cin", ctypes.c_int32), ("pre_act", ctypes.c_int32),
         ("x_f32", ctypes.c_int32), ("y_f32", ctypes.c_int32),
+        ("x_v", ctypes.c_int32), ("y_v", ctypes.c_int32),
     ]
 
 
@@ -125,6 +127,12 @@ def load():
                    ("bsvd_graph_launch", [vp, vp]), ("bsvd_graph_destroy", [vp])):
         getattr(lib, fn).restype = ctypes.c_int
         getattr(lib, fn).argtypes = at
+    lib.bsvd_v_frame_elems.restype = i64
+    lib.bsvd_v_frame_elems.argtypes = [i32, i32, i32, i32]
+    lib.bsvd_v_groups.restype = i32
+    lib.bsvd_v_groups.argtypes = [i32, i32]
+    lib.bsvd_to_v.restype = ctypes.c_int
+    lib.bsvd_to_v.argtypes = [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]
     lib.bsvd_workspace_bytes.restype = i64
     lib.bsvd_workspace_bytes.argtypes = [ctypes.POINTER(BsvdConvArgs)]
     if lib.bsvd_abi_version() != ABI_VERSION:

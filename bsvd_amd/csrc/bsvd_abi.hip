@@ -277,6 +277,68 @@ __global__ void pack_head_weights_kernel(const float *__restrict__ w, const floa
         bp[i] = (bias && i < Cmid) ? bias[i] : 0.f;
 }
 
+// Transformed-domain layout (BsvdConvArgs.x_v / y_v, include/bsvd_hip.h): groups per row, floats per frame
+static inline int v_groups(int W, int m) { return (((W + m - 1) / m) + 7) / 8 * 8; }
+static inline int64_t v_plane_elems(int H, int W, int C, int m) { return (int64_t)H * C * (m + 2) * v_groups(W, m); }
+static inline int64_t v_edge_elems(int H, int W, int C, int m) { return (int64_t)H * ((W + 8 * m - 1) / (8 * m)) * 4 * C; }
+
+// bsvd_to_v: one thread per (frame, row, group, 8-channel block): the A = M + 2 pixels of the group (zero outside the image), BT per channel in
+// fp32 (the kernels' WinoForm<M>::input), every transformed value split into an fp16 pair with the kernels' saturating conversions
+template <int M>
+__global__ void to_v_kernel(const float *__restrict__ x, int64_t x_fs, int x_f32, float *__restrict__ v, int64_t v_fs, int frames, int H, int W,
+                            int C, int wg)
+{
+    constexpr int A = M + 2;
+    using F = WinoForm<M>;
+    fp16_saturate_on();
+    const int c8n = C >> 3;
+    const int64_t total = (int64_t)frames * H * wg * c8n;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % c8n);
+        int64_t r = i / c8n;
+        const int g = (int)(r % wg); r /= wg;
+        const int row = (int)(r % H);
+        const int f = (int)(r / H);
+        const int chunk = c8 >> 1, half = c8 & 1;
+        float d[A][8];
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            const int px = M * g - 1 + a;
+            const bool ok = px >= 0 && px < W;
+            const float *src = x + f * x_fs + ((int64_t)row * W + (ok ? px : 0)) * C;
+            if (x_f32) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d[a][k] = ok ? src[c8 * 8 + k] : 0.f;
+            } else {
+                const _Float16 *hp = reinterpret_cast<const _Float16 *>(src + chunk * 16) + half * 8;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d[a][k] = ok ? (float)hp[k] + (float)hp[16 + k] : 0.f;
+            }
+        }
+        _Float16 hi[A][8], lo[A][8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float din[A], vout[A];
+#pragma unroll
+            for (int a = 0; a < A; ++a) din[a] = d[a][k];
+            F::input(din, vout);
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                hi[a][k] = (_Float16)vout[a];
+                lo[a][k] = (_Float16)__builtin_fmaf((float)hi[a][k], -1.0f, vout[a]);
+            }
+        }
+        float *dst = v + f * v_fs + (int64_t)row * ((int64_t)C * A * wg);
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            float4 *ph = reinterpret_cast<float4 *>(dst + ((int64_t)((chunk * A + a) * 4 + half) * wg + g) * 4);
+            float4 *pl = reinterpret_cast<float4 *>(dst + ((int64_t)((chunk * A + a) * 4 + 2 + half) * wg + g) * 4);
+            *ph = *reinterpret_cast<const float4 *>(hi[a]);
+            *pl = *reinterpret_cast<const float4 *>(lo[a]);
+        }
+    }
+}
+
 static inline unsigned grid_for(int64_t n, int block)
 {
     int64_t g = (n + block - 1) / block;
@@ -363,6 +425,23 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
     p.head_w = nullptr; p.head_bias = nullptr; p.head_cin = 0;
     p.pre_w = nullptr; p.pre_bias = nullptr; p.pre_cin = 0; p.pre_act = 0;
     p.x_f32 = a->x_f32 ? 1 : 0; p.y_f32 = a->y_f32 ? 1 : 0;
+    p.x_v = a->x_v; p.y_v = a->y_v; p.v_wg = 0;
+    if (a->x_v || a->y_v) {
+        const int m = a->wino_m % 10;
+        if (a->dtype != BSVD_F16X3 || !a->w_wino_packed) { set_error("bsvd_conv3x3: x_v / y_v are options of the Winograd form (BSVD_F16X3 + w_wino_packed)"); return -22; }
+        if ((a->x_v && a->x_v != m) || (a->y_v && a->y_v != m)) { set_error("bsvd_conv3x3: x_v / y_v (%d / %d) must be the form's m = %d", a->x_v, a->y_v, m); return -22; }
+        if ((a->x_v && a->x_f32) || (a->y_v && a->y_f32)) { set_error("bsvd_conv3x3: a tensor is either plain fp32 or transformed, not both"); return -22; }
+        if (a->y_v && a->epilogue != BSVD_EPI_PLAIN) { set_error("bsvd_conv3x3: y_v needs the PLAIN epilogue"); return -22; }
+        if (a->x_v && a->fold > 0 && ((a->halo_prev && ((a->halo_prev_pstride & 15) || (a->halo_prev_coff & 15))) ||
+                                      (a->halo_next && ((a->halo_next_pstride & 15) || (a->halo_next_coff & 15))))) {
+            set_error("bsvd_conv3x3: x_v halos: pstride and coff are channel counts of transformed tensors (multiples of 16)"); return -22;
+        }
+        p.v_wg = v_groups(a->W, m);
+        const int64_t vfe = v_plane_elems(a->H, a->W, a->x_v ? a->Cin : a->Cout, m);
+        if (a->x_v && (a->frames > 1 && a->x_frame_stride < v_plane_elems(a->H, a->W, a->Cin, m))) { set_error("bsvd_conv3x3: x_v: x_frame_stride < the transformed frame"); return -22; }
+        if (a->y_v && a->y_frame_stride < bsvd_v_frame_elems(a->H, a->W, a->Cout, m)) { set_error("bsvd_conv3x3: y_v: y_frame_stride < bsvd_v_frame_elems"); return -22; }
+        if (vfe * 4 >= 0x7fffffffLL) { set_error("bsvd_conv3x3: transformed frame >= 2 GiB"); return -22; }
+    }
     if (a->x_f32 && !(a->dtype == BSVD_F16X3 && a->w_wino_packed)) { set_error("bsvd_conv3x3: x_f32 is the Winograd form's input option (BSVD_F16X3 + w_wino_packed)"); return -21; }
     if (a->y_f32 && (a->dtype != BSVD_F16X3 || a->y_planar_ch > 0 || a->x_planar_ch > 0 || a->epilogue == BSVD_EPI_RESID || a->pre_w_packed || a->head_w_packed ||
                      (a->epilogue == BSVD_EPI_PS_ADD && !a->w_wino_packed))) {
@@ -440,6 +519,31 @@ static int conv3x3_impl(const BsvdConvArgs *a, void *stream, char *name, int nam
 }
 
 int bsvd_conv3x3(const BsvdConvArgs *a, void *stream) { return conv3x3_impl(a, stream, nullptr, 0); }
+
+int32_t bsvd_v_groups(int32_t W, int32_t m) { return (m == 2 || m == 4 || m == 6) && W > 0 ? v_groups(W, m) : -1; }
+
+int64_t bsvd_v_frame_elems(int32_t H, int32_t W, int32_t C, int32_t m)
+{
+    if (!(m == 2 || m == 4 || m == 6) || H <= 0 || W <= 0 || C <= 0 || (C & 15)) { set_error("bsvd_v_frame_elems: m = 2 | 4 | 6, C %% 16 == 0"); return -1; }
+    return v_plane_elems(H, W, C, m) + v_edge_elems(H, W, C, m);
+}
+
+int bsvd_to_v(const void *x, int64_t x_fs, int32_t x_f32, void *v, int64_t v_fs, int32_t frames, int32_t H, int32_t W, int32_t C, int32_t m,
+              void *stream)
+{
+    if (!x || !v || frames <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 15)) { set_error("bsvd_to_v: bad arguments (C %% 16 == 0)"); return -3; }
+    if (!(m == 2 || m == 4 || m == 6)) { set_error("bsvd_to_v: m = %d (2, 4 or 6)", m); return -2; }
+    if ((((uintptr_t)x) & 15) || (((uintptr_t)v) & 15) || (v_fs & 3)) { set_error("bsvd_to_v: 16-byte aligned tensors"); return -3; }
+    if (v_fs < bsvd_v_frame_elems(H, W, C, m)) { set_error("bsvd_to_v: v_frame_stride < bsvd_v_frame_elems"); return -3; }
+    const int wg = v_groups(W, m);
+    hipError_t e = hipMemsetAsync(v, 0, (size_t)frames * v_fs * 4, (hipStream_t)stream);        // pad groups and the edge record: zeros
+    if (e != hipSuccess) return (int)e;
+    const int64_t total = (int64_t)frames * H * wg * (C >> 3);
+    if (m == 2) hipLaunchKernelGGL(to_v_kernel<2>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float *)x, x_fs, x_f32, (float *)v, v_fs, frames, H, W, C, wg);
+    else if (m == 4) hipLaunchKernelGGL(to_v_kernel<4>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float *)x, x_fs, x_f32, (float *)v, v_fs, frames, H, W, C, wg);
+    else hipLaunchKernelGGL(to_v_kernel<6>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float *)x, x_fs, x_f32, (float *)v, v_fs, frames, H, W, C, wg);
+    return (int)hipGetLastError();
+}
 
 int bsvd_conv3x3_variant(const BsvdConvArgs *a, char *name, int32_t name_len)
 {

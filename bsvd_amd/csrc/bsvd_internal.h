@@ -41,6 +41,9 @@ struct ConvParams {
     int32_t pre_cin, pre_act;
     // BsvdConvArgs.x_f32 / y_f32 (split mode): the input (Winograd form only) / the NHWC output holds plain fp32 channels instead of fp16 pairs
     int32_t x_f32, y_f32;
+    // BsvdConvArgs.x_v / y_v (Winograd form, split mode): the input / output tensor lives in the TRANSFORMED domain of F(wino_m % 10, 3) -- per frame
+    // [row][16-channel chunk][position][quarter][group] x 16 B (conv3x3_winox.hip); v_wg = groups per image row (ceil(W / M) rounded up to 8)
+    int32_t x_v, y_v, v_wg;
     // Winograd form of the wide split-fp16 layers (BsvdConvArgs.w_wino_packed): w then points at the transformed pack
     int32_t fat_min_wgs;     // BsvdConvArgs.fat_min_wgs (0 = default): smallest grid that takes the 128-accumulator split tile
     int32_t wino_m;          // 0 = direct convolution; 2 | 4 | 6 = F(wino_m, 3) along x (conv3x3_winox.hip); 12 | 14 = the all-positions-per-wave kernel (conv3x3_wino.hip)

@@ -228,9 +228,15 @@ __device__ __forceinline__ XChunkSrc x_chunk_src(const XTile t, int cbl)      //
 // computed for it); the body computes C::TR <= GTR of them from the tile's first row (winox_kernel_tail: the last row band of a
 // 135- or 120-row layer has <= 8 live rows and runs the 8-row body on the 16-row grid).
 // FG: 0 the plain grid; 1 / 2 the launch's grid may be a folded one (wx_grid): 1 = this workgroup runs a regular tile of it, 2 = a folded tile.
-template <int M, int NH, int NTW, int MT, bool PERSIST, bool XF, int GTR, int FG = 0>
+// XF == 2 (BsvdConvArgs.x_v): the input tensor (and its halos) is already in the TRANSFORMED domain -- its producer's epilogue applied BT and split
+// the values: per frame [row][16-channel chunk][position xi][quarter: hi c0-7, hi c8-15, lo c0-7, lo c8-15][group of M pixels] x 16 B,
+// i.e. exactly the LDS planes of a chunk with the groups of a whole image row side by side.  The K loop's "transform" is then a copy: 16-byte
+// units global -> registers -> ds_write_b128, the LDS image linear in the unit index; no VALU work beside the MFMA waves at all.
+template <int M, int NH, int NTW, int MT, bool PERSIST, int XF, int GTR, int FG = 0>
 __device__ __forceinline__ void winox_tile(const ConvParams &p)
 {
+    constexpr bool XV = XF == 2;
+    static_assert(!XV || (FG == 0 && !PERSIST), "transformed-domain input: the plain tile grid");
     using C = XCfg<M, NH, NTW, MT, PERSIST, FG == 2>;
     using F = WinoForm<M>;
     constexpr int A = C::A;
@@ -254,7 +260,8 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
     const int q8 = ntiles >> 3, r8 = ntiles & 7;
     const int xcd_first = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, xcd_count = q8 + (xcd < r8 ? 1 : 0);
     const int xcd_wgs = ((int)gridDim.x - xcd + 7) >> 3;      // workgroups of this launch on this XCD (== xcd_count when not persistent)
-    const unsigned hw = (unsigned)p.H * (unsigned)p.W;
+    // (XV: a "pixel" of the byte arithmetic below is one (row, group, position) slot: v_wg groups x A positions per row)
+    const unsigned hw = XV ? (unsigned)p.H * (unsigned)(A * p.v_wg) : (unsigned)p.H * (unsigned)p.W;
     auto decode_tile = [&](int j) __attribute__((always_inline)) {      // j: index into this XCD's range; beyond it: a dead tile
         XTile t;
         const bool live = j < xcd_count;
@@ -363,7 +370,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
     MixConst mixk = {1.0f, -1.0f};
     asm volatile("" : "+s"(mixk.one), "+s"(mixk.mone));         // opaque: see dec_pair / split_pair
     constexpr int CH = C::NTHREADS == 512 ? 2 : 4;        // channels per transform item (512-thread workgroups: 4-byte loads, two items per lane)
-    static_assert(!XF || CH == 2, "fp32 input: the 2-channel items of the 512-thread workgroups");
+    static_assert(XF != 1 || CH == 2, "fp32 input: the 2-channel items of the 512-thread workgroups");
     constexpr int NDW = CH / 2;                                   // dwords per pixel and part
     struct Raw { unsigned h[A][NDW], l[A][NDW]; };
     // item -> lane order: the two 8-channel quarters of a slot on ADJACENT lanes (8 (4) consecutive lanes read 32 contiguous bytes of one pixel:
@@ -386,7 +393,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
             row = up ? row - C::PRH : row;
             gx0 = up ? gx0 + C::TWPX : gx0;
         }
-        if constexpr (XF) {
+        if constexpr (XF == 1) {
             // fp32 channels: the item's two channels 8 qb + sub / 2, + 1 are 8 contiguous bytes (8 adjacent lanes = one pixel's 64-byte chunk)
             const unsigned base = active ? (unsigned)((c.oy0 - 1 + row) * p.W + gx0) * c.ps4 + (unsigned)(qb * 32 + 2 * sub) : BSVD_WX_OOB;
             if (c.x_inside) {            // interior tile: scalar position offsets (see below)
@@ -441,7 +448,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
         int row, qb, g, sub;
         item_geom(E, row, qb, g, sub);
         unsigned char *dst = vbuf + qb * C::PLANE + (row * 8 + g) * 16 + sub;
-        if constexpr (XF) {
+        if constexpr (XF == 1) {
             // channel by channel (BT on channel PAIRS, v_pk_add_f32: 5-7 % slower per layer -- packed fp32 beside MFMA waves, r05e)
             float d0[A], d1[A], v0[A], v1[A];
             float v[A][2];
@@ -523,8 +530,36 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
     constexpr int PP = (M == 2 && C::NTHREADS == 512) ? (PERSIST ? 1 : 2) : 1;
     constexpr int NSLOTS = NMAIN;
     Raw raw[PP][NSLOTS], raw_rot[PP];
+    // XV: the chunk's V image is A * 4 planes of NSLOT 16-byte units, linear in the unit index u = plane * NSLOT + row * 8 + group
+    constexpr int VU = A * 4 * C::NSLOT, NVU = (VU + C::NTHREADS - 1) / C::NTHREADS;
+    [[maybe_unused]] f32x4 rawv[XV ? PP : 1][XV ? NVU : 1];
+    [[maybe_unused]] auto v_load = [&](int cc, int SET, int tl) __attribute__((always_inline)) {
+        XChunkSrc c;
+        if (cc >= T.S.ncb) c = x_chunk_src(next_tile(), cc - T.S.ncb);
+        else c = x_chunk_src(T, cc);
+        const unsigned aw = (unsigned)(A * p.v_wg);
+        const unsigned rowpitch = c.ps4 * aw, plane_b = (unsigned)p.v_wg * 16u;       // bytes: one image row of the holding tensor, one (xi, quarter) plane of a row
+        const unsigned soff = c.soff * aw;                                           // this chunk inside the holding tensor's row
+        const int g0 = c.ox0 / M;
+#pragma unroll
+        for (int k = 0; k < NVU; ++k) {
+            const int u = k * C::NTHREADS + wid * 64 + tl;
+            const int pl = u / C::NSLOT, sl = u - pl * C::NSLOT;
+            // rows outside the image fall outside the descriptor (a negative row wraps beyond 2 GiB); the groups of a tile always exist (v_wg % 8 == 0)
+            const unsigned voff = (unsigned)((c.oy0 - 1 + (sl >> 3)) * (int)rowpitch) + (unsigned)pl * plane_b + (unsigned)(g0 + (sl & 7)) * 16u;
+            rawv[SET][k] = buf_load4(c.rs, (VU % C::NTHREADS == 0 || u < VU) ? voff : BSVD_WX_OOB, soff);
+        }
+    };
+    [[maybe_unused]] auto v_finish = [&](unsigned char *vbuf, int SET, int tl) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NVU; ++k) {
+            const int u = k * C::NTHREADS + wid * 64 + tl;
+            if (VU % C::NTHREADS == 0 || u < VU) *reinterpret_cast<f32x4 *>(vbuf + u * 16) = rawv[SET][k];
+        }
+    };
     using PAll = std::integral_constant<int, 3>;     // part_: 1 the lanes' main items, 2 the rotating left-over block, 3 both
     auto chunk_load = [&](int cc, int SET, auto part_, int tl) __attribute__((always_inline)) {
+        if constexpr (XV) { v_load(cc, SET, tl); return; }
         // beyond T's last chunk: the first chunks of the workgroup's next tile (or of a dead tile: zeros)
         XChunkSrc c;
         if (cc >= T.S.ncb) c = x_chunk_src(next_tile(), cc - T.S.ncb);
@@ -539,6 +574,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
         }
     };
     auto chunk_finish = [&](int cc, unsigned char *vbuf, int SET, auto part_, int tl) __attribute__((always_inline)) {
+        if constexpr (XV) { v_finish(vbuf, SET, tl); return; }
         if constexpr (decltype(part_)::value & 1) {
 #pragma unroll
         for (int k = 0; k < NMAIN; ++k) item_finish(vbuf, main_E(k, tl), main_active(k, tl), raw[SET][k]);
@@ -838,7 +874,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
 #endif
 }
 
-template <int M, int NH, int NTW, int MT, bool PERSIST, bool XF = false>
+template <int M, int NH, int NTW, int MT, bool PERSIST, int XF = 0>
 __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M, NH, NTW, MT, PERSIST>::NW / 4 * XCfg<M, NH, NTW, MT, PERSIST>::WGS)) void winox_kernel(const ConvParams p)
 {
     winox_tile<M, NH, NTW, MT, PERSIST, XF, XCfg<M, NH, NTW, MT, PERSIST>::TR>(p);
@@ -854,11 +890,11 @@ constexpr bool wx_tail_folds(int m) { return BSVD_WX_TAIL == 2 && m == 2; }
 // 480 x 856): those workgroups run the 8-row body -- the same instruction sequence per output (bit-identical, like the 8-row tile of
 // small grids), 0.57 of a full tile's time for tiles that are <= half alive.  A wave-uniform branch at the very top, two complete
 // bodies: nothing inside the K loops knows about it (the in-loop form, BSVD_WX_DEADROWS, cost every tile its MFMA schedule).
-template <int M, int NH, int NTW, bool XF>
+template <int M, int NH, int NTW, int XF>
 __global__ __launch_bounds__((XCfg<M, NH, NTW, 4, false>::NTHREADS), (XCfg<M, NH, NTW, 4, false>::NW / 4)) void winox_kernel_tail(const ConvParams p)
 {
     // this workgroup's tile, decoded like winox_tile does (XCD-contiguous tile ranges, optional reverse walk)
-    constexpr bool FOLDS = wx_tail_folds(M);
+    constexpr bool FOLDS = wx_tail_folds(M) && XF != 2;       // (transformed-domain input: the 8-row body for the short band, like F(6,3))
     const WxGrid G = wx_grid(p.nty, p.ntx, p.nct, p.Ho, FOLDS);
     const int ntiles = p.frames * G.per_frame;
     const int bid = blockIdx.x, xcd = bid & 7;
@@ -875,17 +911,21 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, 4, false>::NTHREADS), (XCfg<M, NH
     }
 }
 
-template <int M, int NH, int NTW, int MT = 4, bool PERSIST = false, bool XF = false>
+template <int M, int NH, int NTW, int MT = 4, bool PERSIST = false, int XF = 0>
 static int launch_winox_cfg(const ConvParams &pin, hipStream_t stream, char *name, int name_len, int max_wgs = BSVD_CUS)
 {
     using C = XCfg<M, NH, NTW, MT, PERSIST>;
-    if constexpr (!XF && !PERSIST && C::NTHREADS == 512 && (M == 2 || M == 6)) {      // the product configurations exist for both input formats
-        if (pin.x_f32) return launch_winox_cfg<M, NH, NTW, MT, PERSIST, true>(pin, stream, name, name_len, max_wgs);
-    } else if constexpr (!XF) {
+    if constexpr (XF == 0 && !PERSIST && C::NTHREADS == 512 && (M == 2 || M == 6)) {      // the product configurations exist for every input format
+        if (pin.x_f32) return launch_winox_cfg<M, NH, NTW, MT, PERSIST, 1>(pin, stream, name, name_len, max_wgs);
+        if (pin.x_v) return launch_winox_cfg<M, NH, NTW, MT, PERSIST, 2>(pin, stream, name, name_len, max_wgs);
+    } else if constexpr (XF == 0 && !PERSIST && M == 4) {        // (measurement builds: F(4,3) reads transformed tensors too)
+        if (pin.x_v) return launch_winox_cfg<M, NH, NTW, MT, PERSIST, 2>(pin, stream, name, name_len, max_wgs);
         if (pin.x_f32) { set_error("bsvd_conv3x3: x_f32 is not available for this Winograd variant"); return -19; }
+    } else if constexpr (XF == 0) {
+        if (pin.x_f32 || pin.x_v) { set_error("bsvd_conv3x3: x_f32 / x_v are not available for this Winograd variant"); return -19; }
     }
     if (name) {
-        snprintf(name, name_len, "winox_kernel<F(%d,3),%dx%d>[f16x3]%s%s%s", M, NH, NTW, MT == 2 ? "[8 rows]" : "", PERSIST ? "[persistent]" : "", XF ? "[f32 in]" : "");
+        snprintf(name, name_len, "winox_kernel<F(%d,3),%dx%d>[f16x3]%s%s%s", M, NH, NTW, MT == 2 ? "[8 rows]" : "", PERSIST ? "[persistent]" : "", XF == 2 ? "[V in]" : XF ? "[f32 in]" : "");
         return 0;
     }
     ConvParams p = pin;
@@ -893,12 +933,12 @@ static int launch_winox_cfg(const ConvParams &pin, hipStream_t stream, char *nam
     p.nty = (p.Ho + C::TR - 1) / C::TR;
     p.nct = (p.Cout + C::BN - 1) / C::BN;
     constexpr bool TAILK = BSVD_WX_TAIL && MT == 4 && !PERSIST && C::NTHREADS == 512 && (M == 2 || M == 6);
-    const int64_t nblk = (int64_t)p.frames * wx_grid(p.nty, p.ntx, p.nct, p.Ho, TAILK && wx_tail_folds(M)).per_frame;
+    const int64_t nblk = (int64_t)p.frames * wx_grid(p.nty, p.ntx, p.nct, p.Ho, TAILK && wx_tail_folds(M) && XF != 2).per_frame;
     if (nblk <= 0 || nblk > 0x7fffffff) { set_error("bsvd_conv3x3: grid of %lld workgroups", (long long)nblk); return -1; }
     // the product's 16-row tile launches are ALL this kernel (one symbol per form in a profile): a grid without such a band never takes
     // the branch
     if constexpr (TAILK) {
-        static_assert(XCfg<M, NH, NTW, 4, false, wx_tail_folds(M)>::LDS_BYTES == C::LDS_BYTES, "the folded tile's transform buffers fit under the exchange");
+        static_assert(XCfg<M, NH, NTW, 4, false, wx_tail_folds(M) && XF != 2>::LDS_BYTES == C::LDS_BYTES, "the folded tile's transform buffers fit under the exchange");
         static std::atomic<int> granted_t[MAX_DEVICES];
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&winox_kernel_tail<M, NH, NTW, XF>), C::LDS_BYTES, granted_t);
         if (e != hipSuccess) return (int)e;
@@ -967,7 +1007,7 @@ int launch_winox(const ConvParams &p, hipStream_t stream, char *name, int name_l
         const int ntx4 = (p.Wo + C4::TWPX - 1) / C4::TWPX, nct4 = (p.Cout + C4::BN - 1) / C4::BN;
         const int64_t per_row = (int64_t)p.frames * ntx4 * nct4;
         // (the 16-row grid as it is launched: a short last row band folds -- 256 -> 256 on ONE 135 x 240 frame is 240 + 16 = 256 workgroups, one round)
-        const int64_t n4 = (int64_t)p.frames * wx_grid((p.Ho + 15) / 16, ntx4, nct4, p.Ho, wx_tail_folds(2)).per_frame, n2 = per_row * ((p.Ho + 7) / 8);
+        const int64_t n4 = (int64_t)p.frames * wx_grid((p.Ho + 15) / 16, ntx4, nct4, p.Ho, wx_tail_folds(2) && !p.x_v).per_frame, n2 = per_row * ((p.Ho + 7) / 8);
         if (p.wino_m == 2 && n4 < 8 * BSVD_CUS && 0.87 * fill(n2) > fill(n4)) return launch_winox_cfg<2, 2, 2, 2>(p, stream, name, name_len);
 #ifdef BSVD_MEASURE
         // (large grids as 256 persistent workgroups, the transform pipeline running across tile boundaries: built, bit-identical, 6-13 %

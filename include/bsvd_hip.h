@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BSVD_ABI_VERSION 10
+#define BSVD_ABI_VERSION 11
 
 /* dtype.  BSVD_F32: exact fp32 (v_mfma_f32_32x32x2_f32).  BSVD_F16X3 ("split16"): every fp32 value v is carried as
  * an fp16 pair hi = fp16(v), lo = fp16(v - hi); a 16-channel chunk of a pixel is stored as [hi x16 | lo x16] in the
@@ -166,6 +166,24 @@ typedef struct BsvdConvArgs {
      * starts from the value -- no decode, one 8-byte load per position, the transform on channel pairs -- which takes about a fifth off
      * the transform's instructions; values are exact fp32 instead of 22-bit pairs.  Anything else returns -21. */
     int32_t x_f32, y_f32;
+    /* Transformed-domain hand-over between Winograd-form layers (ABI v11, BSVD_F16X3 + w_wino_packed only).  The input
+     * transform of F(m,3) -- V = BT d over the m + 2 pixels of a group, re-split into fp16 pairs -- is a property of the TENSOR, not of its
+     * reader: done in the reader's K loop it is repeated per output-channel tile and its VALU time adds to the MFMA time of the SIMD it
+     * shares.  With y_v != 0 the producer's epilogue does it ONCE, on the fp32 values it holds anyway, and stores the
+     * tensor in the transformed domain; with x_v != 0 the reader's K loop is a plain 16-byte copy into LDS.  Layout of such a tensor, per
+     * frame (bsvd_v_frame_elems(H, W, C, m) floats):
+     *     V[row][C / 16 chunks][m + 2 positions][4 quarters: hi c0-7, hi c8-15, lo c0-7, lo c8-15][Wg groups] x 16 bytes,
+     *         Wg = ceil(W / m) rounded up to a multiple of 8 (a group = m consecutive pixels of a row; position xi of group g =
+     *         sum_i BT[xi][i] * d[m g - 1 + i], pixels outside the image = 0), followed by
+     *     E[row][ceil(W / 8m) tiles][4][C] fp32 -- the producer's per-tile edge record (partial sums of the two positions that need a pixel
+     *         of the neighbouring tile + its own first / last pixel column), consumed by the patch pass that bsvd_conv3x3 issues
+     *         right behind a y_v launch on the same stream (one small second kernel: the only cross-tile dependency of the transform).
+     * x_v / y_v carry the form's m (2, 4 or 6) and must equal wino_m % 10 of the layer (x_v) resp. of the tensor's reader (y_v).
+     * x_v: x AND both halos are such tensors -- halo_*_pstride = channels of the holding tensor, halo_*_coff = first channel, both
+     * multiples of 16, exactly as for NHWC halos; x_frame_stride = elements between frames (>= bsvd_v_frame_elems).
+     * y_v: PLAIN layers of the Winograd kernel whose own form has the same m (the epilogue's pixel groups are the reader's groups);
+     * y_frame_stride likewise.  Not with x_f32 / y_f32 on the same tensor.  Anything else returns -22. */
+    int32_t x_v, y_v;
 } BsvdConvArgs;
 
 int bsvd_abi_version(void);
@@ -175,6 +193,15 @@ int bsvd_conv_args_size(void);   /* sizeof(BsvdConvArgs) as compiled into the li
 #define BSVD_BUILD_MEASURE 1
 int bsvd_build_info(void);
 const char *bsvd_last_error(void);
+
+/* Transformed-domain tensors (BsvdConvArgs.x_v / y_v): floats per frame (V planes + edge record), groups per row, and a stand-alone
+ * transform of an NHWC tensor (x_f32 != 0: plain fp32 channels, else fp16 pairs) into that layout -- what a y_v producer writes, computed
+ * directly (no edge record needed; the E block is zero-filled).  Test / measurement aid and the fallback for a producer that cannot
+ * write the layout itself.  m = 2, 4 or 6; C % 16 == 0. */
+int64_t bsvd_v_frame_elems(int32_t H, int32_t W, int32_t C, int32_t m);
+int32_t bsvd_v_groups(int32_t W, int32_t m);
+int bsvd_to_v(const void *x, int64_t x_frame_stride, int32_t x_f32, void *v, int64_t v_frame_stride, int32_t frames, int32_t H, int32_t W,
+              int32_t C, int32_t m, void *stream);
 
 /* The fused layer above (BSVD_F32: exact fp32 MFMA; BSVD_F16X3: split-fp16 3-pass MFMA). */
 int bsvd_conv3x3(const BsvdConvArgs *args, void *stream);

@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -66,3 +68,16 @@ def test_power_probe_parses_rocm_smi_and_survives_its_absence(tmp_path, monkeypa
     assert calls
     monkeypatch.setenv("PATH", str(tmp_path / "nowhere"))
     assert bench.power_probe(lambda: None, 0.1) is None
+
+
+def test_value_normalised_arithmetic():
+    """bench.normalise_value: a box whose fixed calibration layer takes 5 % longer than the reference box's shows 5 %
+    fewer frames/s on the same commit; the normalised figure undoes exactly that, and is None when a leg is missing."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.normalise_value(366.0, 1.05, 1.00) == pytest.approx(384.3)
+    assert bench.normalise_value(384.4, 1.00, 1.00) == pytest.approx(384.4)
+    assert bench.normalise_value(400.0, 0.95, 1.00) == pytest.approx(380.0)
+    for cal, ref in ((None, 1.0), (1.0, None), (0.0, 1.0), (1.0, 0.0)):
+        assert bench.normalise_value(366.0, cal, ref) is None
+    assert set(bench.BOX_CAL_REF) >= {"direct64_ms", "wino256_ms", "source"} and bench.BOX_CAL_REF["direct64_ms"] > 0

@@ -113,3 +113,38 @@ def test_bench_gpus_2_line_on_one_device():
     assert forwards >= 3 and all(p["exchanges"] == 16 * p["forwards"] and p["forwards"] == forwards for p in per_rank)
     assert per_rank[0]["bytes_sent"] == per_rank[1]["bytes_sent"] > 0 and all(p["host_staged"] for p in per_rank)
     assert "sustained" not in d and "power" not in d           # N = 1 only
+
+
+def test_c4_clip_through_8_ranks_on_one_device_equals_the_unsharded_clip_by_digest():
+    """BASELINE config 4 (one 80-frame 540x960 clip) as the driver will launch it at N = 8 -- here with all 8 ranks on cuda:0, halos host-staged
+    (a path exercise, `degraded`, not a scaling number) -- against the same clip unsharded at N = 1 (`--scaling strong --total-frames 80`):
+    the two lines' per-block output digests must be equal (the denominator of the first real 1 -> 8 curve, and proof that
+    eight frame windows + 16 x 7 x 2 halo exchanges reproduce the whole clip bit for bit at full size)."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--prewarm-s", "0", "--no-power-probe", "--no-box-calibration",
+              "--scaling", "strong", "--total-frames", "80", "--output-digest"]
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", MASTER_ADDR="127.0.0.1")
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, env=env, capture_output=True, text=True,
+                        timeout=900, cwd=root)
+    l1 = [l for l in r1.stdout.splitlines() if l.startswith("{")]
+    assert r1.returncode == 0 and len(l1) == 1, r1.stdout[-2000:] + r1.stderr[-3000:]
+    d1 = json.loads(l1[0])
+    env8 = dict(env, BSVD_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8"] + common
+    r8 = subprocess.run(cmd, env=env8, capture_output=True, text=True, timeout=1500, cwd=root)
+    l8 = [l for l in r8.stdout.splitlines() if l.startswith("{")]
+    assert r8.returncode == 0 and len(l8) == 1, r8.stdout[-2000:] + r8.stderr[-3000:]
+    d8 = json.loads(l8[0])
+    assert d1["config"]["baseline_config"] == d8["config"]["baseline_config"] == "c4"
+    assert d1["n_gpus"] == 1 and d8["n_gpus"] == 8 and d8["config"]["frames_per_gpu"] == 10 and d1["config"]["frames_per_gpu"] == 80
+    assert d8["degraded"] is True and d1["degraded"] is False
+    g1, g8 = d1["output_digest"]["sha256_16_per_10_frame_block"], d8["output_digest"]["sha256_16_per_10_frame_block"]
+    assert len(g1) == len(g8) == 8 and g1 == g8, (g1, g8)
+    per_rank = d8["halo"]["per_rank"]
+    assert [p["rank"] for p in per_rank] == list(range(8)) and all(p["exchanges"] == 16 * p["forwards"] for p in per_rank)
+    assert per_rank[0]["bytes_sent"] == per_rank[7]["bytes_sent"] and per_rank[1]["bytes_sent"] == 2 * per_rank[0]["bytes_sent"]
+    print("C4 on one device: N=1 %.1f frames/s (unsharded 80-frame clip); 8 host-staged ranks on one GPU %.1f frames/s (degraded); digests equal"
+          % (d1["value"], d8["value"]))
