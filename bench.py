@@ -89,17 +89,17 @@ def output_digests(y, first_frame, block=10):
     return out
 
 
-def build_model(device, precision="fp32", blind=False, wide_conv="auto", fuse_pairs="auto", f32_handover="auto"):
+def build_model(device, precision="fp32", blind=False, wide_conv="auto", fuse_pairs="auto", f32_handover="auto", v_handover="auto"):
     import bsvd_amd
     torch.manual_seed(1234)      # random-init weights of the bsvd_c64 architecture (no checkpoint in the tree)
     if blind:                    # options/test/0407...blind_c64.yml:97-121: interm_ch default 30, act default relu
         m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, shift_input=False, in_ch=4, out_ch=3, norm="none",
                           act="relu", interm_ch=30, blind=True, pretrain_ckpt=None, precision=precision, wide_conv=wide_conv,
-                          fuse_pairs=fuse_pairs, f32_handover=f32_handover)
+                          fuse_pairs=fuse_pairs, f32_handover=f32_handover, v_handover=v_handover)
     else:
         m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, shift_input=False, in_ch=4, out_ch=3, norm="none",
                           act="relu6", interm_ch=64, blind=False, pretrain_ckpt=None, precision=precision, wide_conv=wide_conv,
-                          fuse_pairs=fuse_pairs, f32_handover=f32_handover)
+                          fuse_pairs=fuse_pairs, f32_handover=f32_handover, v_handover=v_handover)
     return m.to(device).eval()
 
 
@@ -490,6 +490,8 @@ def main():
                     help="the 64-channel full-resolution conv pairs as one launch each (BSVD(fuse_pairs=...); auto = the product default)")
     ap.add_argument("--f32-handover", default="auto", choices=["auto", "on", "off"],
                     help="tensors only Winograd-form layers read as plain fp32 instead of fp16 pairs (BSVD(f32_handover=...); auto = on)")
+    ap.add_argument("--v-handover", default="auto", choices=["auto", "on", "off"],
+                    help="tensors between two F(6,3) layers in the transformed domain (BSVD(v_handover=...); auto = on where the forms allow)")
     ap.add_argument("--wide-conv", default="auto", help="arithmetic form of the wide split-fp16 layers: auto (= wino2) | direct | wino2 | wino6 | "
                                                         "wino26 (bsvd_amd.engine.WIDE_CONV; the driver's line runs the default)")
     ap.add_argument("--output-digest", action="store_true",
@@ -575,7 +577,7 @@ def main():
         """W untimed + K timed steps of the hot path at `precision`; returns (model, max-over-ranks seconds, per-kernel
         launch timings, last output)."""
         model = build_model(device, precision, wl["blind"], args.wide_conv, {"auto": "auto", "on": True, "off": False}[args.fuse_pairs],
-                            {"auto": "auto", "on": True, "off": False}[args.f32_handover])
+                            {"auto": "auto", "on": True, "off": False}[args.f32_handover], {"auto": "auto", "on": True, "off": False}[args.v_handover])
         ex = model._executor(device)
         halo_fn = None
         if world > 1:
@@ -738,6 +740,7 @@ def main():
                        "baseline_config": ("c4" if frames * world == 80 else args.workload if world == 1 else "c1 x%d" % world) if args.workload == "c1" else args.workload,
                        "frames_per_gpu": frames, "parallelism": "frame-window x%d" % world,
                        "schedule": mode, "halo_transport": halo_transport, "wide_conv": model.wide_conv, "fuse_pairs": model.fuse_pairs,
+                       "v_handover_layers": len(getattr(model._packed, "v_out", ())),
                        "flop_per_frame": flop_per_frame},
             # true when the halo slices of an N>1 run did NOT travel over RCCL/xGMI (host-staged gloo fallback): such a line is a
             # functional check, not a scaling measurement

@@ -122,7 +122,7 @@ def _denblock_params(chns, in_ch, out_ch, interm_ch, blind, norm="none"):
 class _HipNet(nn.Module):
     """Shared engine plumbing of the registered arch classes: NetSpec, precision, weight (re)packing, executor."""
 
-    def _init_engine(self, net, precision, clamp, norm='none', wide_conv='auto', fuse_pairs='auto', f32_handover='auto'):
+    def _init_engine(self, net, precision, clamp, norm='none', wide_conv='auto', fuse_pairs='auto', f32_handover='auto', v_handover='auto'):
         if precision not in ("auto", "fp32", "f16x3"):
             raise ValueError("precision must be 'auto', 'fp32' or 'f16x3'")
         if wide_conv == "auto":
@@ -134,6 +134,9 @@ class _HipNet(nn.Module):
         self.fuse_pairs = FUSE_PAIRS_DEFAULT if fuse_pairs == "auto" else bool(fuse_pairs)
         # tensors only Winograd-form layers read travel as plain fp32 instead of fp16 pairs (engine.F32_HANDOVER_DEFAULT)
         self.f32_handover = None if f32_handover == "auto" else bool(f32_handover)
+        # ... and, between two F(6,3) layers, in the TRANSFORMED domain: the producer's epilogue applies the reader's input transform once
+        # (engine.V_HANDOVER_DEFAULT)
+        self.v_handover = None if v_handover == "auto" else bool(v_handover)
         if norm not in ("none", "bn"):
             raise NotImplementedError("norm=%r: 'none' (the shipped configs, options/test/bsvd_c64.yml:90) and 'bn' (the "
                                       "constructor default; eval-mode statistics folded into the packed conv weights) are "
@@ -247,7 +250,7 @@ class _HipNet(nn.Module):
                                "running statistics; call .eval() first (DenoisingModel.test and profile.py do: "
                                "denoising_model.py:180, profile.py:80).  Training is out of scope of this engine.")
         require_hip()
-        sig = (self._signature(), str(device), self._precision_init, self.wide_conv, self.fuse_pairs, self.f32_handover)
+        sig = (self._signature(), str(device), self._precision_init, self.wide_conv, self.fuse_pairs, self.f32_handover, self.v_handover)
         if self._packed is None or self._packed_sig != sig:
             # every re-pack starts from the precision the constructor resolved: 'auto' that fell back to exact fp32 because ONE
             # checkpoint's folded weights left fp16's range takes the split mode again when an in-range checkpoint is loaded
@@ -272,7 +275,7 @@ class _HipNet(nn.Module):
                         raise ValueError("precision='f16x3': max |weight| after the BatchNorm fold is %.3g, outside fp16's "
                                          "range (use precision='fp32' or 'auto')" % wmax)
             self._packed = PackedNet(self.net, state, device, self.precision, self.wide_conv, fuse_pairs=self.fuse_pairs,
-                                     f32_handover=self.f32_handover)
+                                     f32_handover=self.f32_handover, v_handover=self.v_handover)
             self._packed_sig = sig
             self._exec = HipExecutor(self._packed)
             self._exec_gen = getattr(self, "_exec_gen", 0) + 1
@@ -343,14 +346,14 @@ class BSVD(_HipNet):
     def __init__(self, chns=[32, 64, 128], mid_ch=3, shift_input=False, in_ch=4, out_ch=3, norm='bn', act='relu',
                  interm_ch=30, blind=False, pretrain_ckpt='./experiments/pretrained_ckpt/bsvd-64.pth',
                  engine_mode='auto', clamp=None, precision='auto', stream_overlap=True, stream_rings=True,
-                 stream_graphs=True, stream_chunk='auto', wide_conv='auto', fuse_pairs='auto', f32_handover='auto'):
+                 stream_graphs=True, stream_chunk='auto', wide_conv='auto', fuse_pairs='auto', f32_handover='auto', v_handover='auto'):
         super().__init__()
         if shift_input:
             raise NotImplementedError("shift_input=True (CvBlock input stage) is not used by any BSVD config; "
                                       "the reference itself is inconsistent there (SURVEY.md §8a-16)")
         if engine_mode not in ("auto", "clip", "stream"):
             raise ValueError("engine_mode must be 'auto', 'clip' or 'stream'")
-        self._init_engine(make_netspec(chns, mid_ch, in_ch, out_ch, act, interm_ch, blind), precision, clamp, norm, wide_conv, fuse_pairs, f32_handover)
+        self._init_engine(make_netspec(chns, mid_ch, in_ch, out_ch, act, interm_ch, blind), precision, clamp, norm, wide_conv, fuse_pairs, f32_handover, v_handover)
         self.engine_mode = engine_mode
         self.last_mode = None          # schedule the last forward() actually ran ('clip' | 'stream')
         self.stream_overlap = bool(stream_overlap)   # streaming_forward: temp1(step k) and temp2(step k-1) as parallel graph branches
@@ -453,7 +456,7 @@ class BSVD(_HipNet):
         held = sum(e.ring_bytes for e in self._stream_engs.values())
         n = self.AUTO_CHUNK_MAX
         while n >= 2:
-            if n <= F and ring_bytes_estimate(self.net, H, W, n) <= 0.5 * (free + held):
+            if n <= F and ring_bytes_estimate(self.net, H, W, n, getattr(getattr(self, "_packed", None), "v_out", ())) <= 0.5 * (free + held):
                 return n
             n //= 2
         return 1
@@ -724,7 +727,7 @@ class TSN(_HipNet):
 
     def __init__(self, num_segments=11, base_model='WNet_multistage', shift_type='TSM', shift_div=8, inplace=False,
                  net2d_opt={}, enable_past_buffer=True, clamp=None, precision='auto', wide_conv='auto', fuse_pairs='auto',
-                 f32_handover='auto', **kwargs):
+                 f32_handover='auto', v_handover='auto', **kwargs):
         super().__init__()
         if base_model != 'WNet_multistage':
             raise NotImplementedError("base_model %r" % (base_model,))
@@ -738,7 +741,7 @@ class TSN(_HipNet):
         self.num_segments = num_segments
         self.enable_past_buffer = enable_past_buffer
         self._init_engine(make_netspec(o['chns'], o['mid_ch'], o['in_ch'], o['out_ch'], o['act'], o['interm_ch'],
-                                       o['blind']), precision, clamp, o['norm'], wide_conv, fuse_pairs, f32_handover)
+                                       o['blind']), precision, clamp, o['norm'], wide_conv, fuse_pairs, f32_handover, v_handover)
         n = self.net
         stages = []
         for args_ in ((o['in_ch'], o['mid_ch'], o['blind']), (o['mid_ch'], o['out_ch'], False)):

@@ -279,7 +279,7 @@ __global__ void pack_head_weights_kernel(const float *__restrict__ w, const floa
 
 // Transformed-domain layout (BsvdConvArgs.x_v / y_v, include/bsvd_hip.h): groups per row, floats per frame
 static inline int v_groups(int W, int m) { return (((W + m - 1) / m) + 7) / 8 * 8; }
-static inline int64_t v_plane_elems(int H, int W, int C, int m) { return (int64_t)H * C * (m + 2) * v_groups(W, m); }
+static inline int64_t v_plane_elems(int H, int W, int C, int m) { return (int64_t)H * (v_groups(W, m) / 8) * (C / 16) * v_block_floats(m); }
 static inline int64_t v_edge_elems(int H, int W, int C, int m) { return (int64_t)H * ((W + 8 * m - 1) / (8 * m)) * 4 * C; }
 
 // bsvd_to_v: one thread per (frame, row, group, 8-channel block): the A = M + 2 pixels of the group (zero outside the image), BT per channel in
@@ -328,13 +328,22 @@ __global__ void to_v_kernel(const float *__restrict__ x, int64_t x_fs, int x_f32
                 lo[a][k] = (_Float16)__builtin_fmaf((float)hi[a][k], -1.0f, vout[a]);
             }
         }
-        float *dst = v + f * v_fs + (int64_t)row * ((int64_t)C * A * wg);
+        // block (row, tile g / 8, chunk): [position][quarter][8 groups] x 16 B, then the edge line [side][quarter] x 16 B
+        constexpr int BLK = v_block_floats(M);
+        float *dst = v + f * v_fs + ((int64_t)(row * (wg >> 3) + (g >> 3)) * (C >> 4) + chunk) * BLK;
+        const int gl = g & 7;
 #pragma unroll
         for (int a = 0; a < A; ++a) {
-            float4 *ph = reinterpret_cast<float4 *>(dst + ((int64_t)((chunk * A + a) * 4 + half) * wg + g) * 4);
-            float4 *pl = reinterpret_cast<float4 *>(dst + ((int64_t)((chunk * A + a) * 4 + 2 + half) * wg + g) * 4);
-            *ph = *reinterpret_cast<const float4 *>(hi[a]);
-            *pl = *reinterpret_cast<const float4 *>(lo[a]);
+            *reinterpret_cast<float4 *>(dst + ((a * 4 + half) * 8 + gl) * 4) = *reinterpret_cast<const float4 *>(hi[a]);
+            *reinterpret_cast<float4 *>(dst + ((a * 4 + 2 + half) * 8 + gl) * 4) = *reinterpret_cast<const float4 *>(lo[a]);
+        }
+        if (gl == 0) {
+            *reinterpret_cast<float4 *>(dst + A * 128 + half * 4) = *reinterpret_cast<const float4 *>(hi[0]);
+            *reinterpret_cast<float4 *>(dst + A * 128 + (2 + half) * 4) = *reinterpret_cast<const float4 *>(lo[0]);
+        }
+        if (gl == 7) {
+            *reinterpret_cast<float4 *>(dst + A * 128 + (4 + half) * 4) = *reinterpret_cast<const float4 *>(hi[A - 1]);
+            *reinterpret_cast<float4 *>(dst + A * 128 + (6 + half) * 4) = *reinterpret_cast<const float4 *>(lo[A - 1]);
         }
     }
 }

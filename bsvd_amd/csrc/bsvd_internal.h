@@ -49,6 +49,12 @@ struct ConvParams {
     int32_t wino_m;          // 0 = direct convolution; 2 | 4 | 6 = F(wino_m, 3) along x (conv3x3_winox.hip); 12 | 14 = the all-positions-per-wave kernel (conv3x3_wino.hip)
 };
 
+// Transformed-domain layout (include/bsvd_hip.h, BsvdConvArgs.x_v / y_v): a frame is [row][tile of 8 groups][16-channel chunk] BLOCKS of
+// v_block_floats(m): (m + 2) positions x 4 quarters x 8 groups x 16 B (the LDS planes of one patch row of one chunk, 4 KB for F(6,3)) + one
+// 128-byte EDGE LINE [side 0 | 1][4 quarters] x 16 B: position 0 of the tile's first group resp. position m + 1 of its last group, which need a pixel of
+// the neighbouring tile -- readers take these two values from the edge line (written by the patch pass behind the producer), never from the planes.
+__host__ __device__ constexpr int v_block_floats(int m) { return ((m + 2) * 4 * 8 + 8) * 4; }
+
 void set_error(const char *fmt, ...);
 
 // Experiment knob: keep only the top BSVD_TUNE_LO_BITS mantissa bits of the `lo` half of a split16 pair (10 = all;

@@ -1544,8 +1544,16 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
             return launch_pref<ConvCfg<4, 1, 2, 2, 1, 3>>(p, stream, name, name_len);
         }
         if (stride == 2) {
-            // 8 x 16-px tile, ONE patch buffer (a double-buffered patch leaves 1-2 workgroups per CU: slower, r01 / r02)
-            return launch_cfg<ConvCfg<2, 2, 2, 2, 2, 3, false>, true, 1>(p, stream, name, name_len);
+            // (the tile's register double buffer reads every chunk from the frame itself: a stride-2 layer with a temporal shift -- none exists in the
+            //  reference, DownBlock is a plain conv, bsvd_arch.py:229-255 -- is refused, never computed from the wrong frames)
+            if (p.fold != 0) { set_error("bsvd_conv3x3: BSVD_F16X3 stride-2 layers are plain convs (fold must be 0, got %d)", p.fold); return -17; }
+            // 8 x 16-px x 128-ch workgroup, ONE patch buffer (a double-buffered patch leaves 1-2 workgroups per CU: slower, r01 / r02), every wave
+            // 128 px x 32 ch (<4,1,1,4,2>) since round 6: what this tile waits for is its weight stream -- TCP_PENDING_STALL_CYCLES = 41-51 % of
+            // the kernel's time (profiles/r06f_stride2_pmc.txt), the K loop at 55 % of the MFMA pipe with three waves per SIMD
+            // (r06f_stride2_timeline.txt) -- and the 32-channel wave tile pulls half the weight bytes per MFMA through the L1 (twice the pixel-fragment
+            // reads from LDS): 2.32 -> 2.21 ms per C1 clip for the four launches, same bits (r06g_stride2_variants*.txt).  Refuted before: memory-side
+            // re-fetches (r04), LDS bank conflicts (r05), and in round 6 the item decode at the chunk boundaries (a map with one v_add per item: +1 %).
+            return launch_cfg<ConvCfg<4, 1, 1, 4, 2, 3, false>, true, 1>(p, stream, name, name_len);
         }
         // The fat tiles run one workgroup per CU, so they need a grid of several rounds of 256; small launches
         // (streaming mode: one frame per launch) keep the 64x64 tiles at 3 workgroups per CU.

@@ -41,7 +41,7 @@
 #endif
 #define BSVD_CUS 256       // MI355X: 256 CUs, one 8-wave workgroup of this kernel each (the tile choice of small grids, launch_winox)
 #ifndef BSVD_WX_ABL
-#define BSVD_WX_ABL 0      // TIMING-ONLY ablations (results wrong): 1 no transform in the K loop, 2 no MFMA steps, 4 no epilogue finish, 8 no chunk barrier, 16 transform without its global loads (constant operands: also removes operand toggling), 32 transform without its LDS stores, 64 the K loop re-transforms the prologue's raw registers (no activation loads in the loop, realistic operand values)
+#define BSVD_WX_ABL 0      // TIMING-ONLY ablations (results wrong): 1 no transform in the K loop, 2 no MFMA steps, 4 no epilogue finish, 8 no chunk barrier, 16 transform without its global loads (constant operands: also removes operand toggling), 32 transform without its LDS stores, 64 the K loop re-transforms the prologue's raw registers (no activation loads in the loop, realistic operand values), 128 the transformed-domain epilogue without its plane stores, 256 without its edge-record stores, 512 no patch pass behind it
 #endif
 
 namespace bsvd {
@@ -61,6 +61,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -232,10 +233,16 @@ __device__ __forceinline__ XChunkSrc x_chunk_src(const XTile t, int cbl)      //
 // the values: per frame [row][16-channel chunk][position xi][quarter: hi c0-7, hi c8-15, lo c0-7, lo c8-15][group of M pixels] x 16 B,
 // i.e. exactly the LDS planes of a chunk with the groups of a whole image row side by side.  The K loop's "transform" is then a copy: 16-byte
 // units global -> registers -> ds_write_b128, the LDS image linear in the unit index; no VALU work beside the MFMA waves at all.
-template <int M, int NH, int NTW, int MT, bool PERSIST, int XF, int GTR, int FG = 0>
+// YV (BsvdConvArgs.y_v): the epilogue writes the output in the transformed domain of the SAME form (its pixel groups are the reader's groups): the
+// finisher of a group holds its M output pixels x 8 channels in fp32, fetches the two neighbouring pixels from the lanes of the neighbouring
+// groups (ds_bpermute), applies BT, splits and stores A x (16 B hi + 16 B lo).  The two positions of a tile's first / last group that need a
+// pixel of the NEIGHBOURING TILE are written as partial sums and recorded -- with the tile's own edge columns -- in the frame's edge block; the
+// patch pass behind the launch (v_patch_kernel) completes them.
+template <int M, int NH, int NTW, int MT, bool PERSIST, int XF, int GTR, int FG = 0, bool YV = false>
 __device__ __forceinline__ void winox_tile(const ConvParams &p)
 {
     constexpr bool XV = XF == 2;
+    static_assert(!YV || (FG == 0 && !PERSIST), "transformed-domain output: the plain tile grid");
     static_assert(!XV || (FG == 0 && !PERSIST), "transformed-domain input: the plain tile grid");
     using C = XCfg<M, NH, NTW, MT, PERSIST, FG == 2>;
     using F = WinoForm<M>;
@@ -261,7 +268,7 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
     const int xcd_first = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, xcd_count = q8 + (xcd < r8 ? 1 : 0);
     const int xcd_wgs = ((int)gridDim.x - xcd + 7) >> 3;      // workgroups of this launch on this XCD (== xcd_count when not persistent)
     // (XV: a "pixel" of the byte arithmetic below is one (row, group, position) slot: v_wg groups x A positions per row)
-    const unsigned hw = XV ? (unsigned)p.H * (unsigned)(A * p.v_wg) : (unsigned)p.H * (unsigned)p.W;
+    const unsigned hw = XV ? (unsigned)p.H * (unsigned)(p.v_wg >> 3) * ((unsigned)v_block_floats(M) / 16u) : (unsigned)p.H * (unsigned)p.W;
     auto decode_tile = [&](int j) __attribute__((always_inline)) {      // j: index into this XCD's range; beyond it: a dead tile
         XTile t;
         const bool live = j < xcd_count;
@@ -530,23 +537,30 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
     constexpr int PP = (M == 2 && C::NTHREADS == 512) ? (PERSIST ? 1 : 2) : 1;
     constexpr int NSLOTS = NMAIN;
     Raw raw[PP][NSLOTS], raw_rot[PP];
-    // XV: the chunk's V image is A * 4 planes of NSLOT 16-byte units, linear in the unit index u = plane * NSLOT + row * 8 + group
+    // XV: the chunk's LDS image is A * 4 planes of NSLOT 16-byte units, linear in the unit index u = plane * NSLOT + row * 8 + group: a wave's 64 lanes
+    // write 1 KB of consecutive LDS and read eight 128-byte lines (one per patch row) of the tensor's [row][tile][chunk] blocks.  (Unit order
+    // [row][plane][group] -- 1 KB of consecutive global memory per wave, the planes' segments 2304 B apart in LDS -- measured 3-4 % slower per layer:
+    // profiles/r06e_v_layers_blocks.txt.)
     constexpr int VU = A * 4 * C::NSLOT, NVU = (VU + C::NTHREADS - 1) / C::NTHREADS;
+    constexpr unsigned BLKB = (unsigned)v_block_floats(M) * 4u;
     [[maybe_unused]] f32x4 rawv[XV ? PP : 1][XV ? NVU : 1];
     [[maybe_unused]] auto v_load = [&](int cc, int SET, int tl) __attribute__((always_inline)) {
         XChunkSrc c;
         if (cc >= T.S.ncb) c = x_chunk_src(next_tile(), cc - T.S.ncb);
         else c = x_chunk_src(T, cc);
-        const unsigned aw = (unsigned)(A * p.v_wg);
-        const unsigned rowpitch = c.ps4 * aw, plane_b = (unsigned)p.v_wg * 16u;       // bytes: one image row of the holding tensor, one (xi, quarter) plane of a row
-        const unsigned soff = c.soff * aw;                                           // this chunk inside the holding tensor's row
-        const int g0 = c.ox0 / M;
+        // bytes: the holding tensor's chunks of one tile (ps4 = its channels x 4 -> channels / 16 blocks), one image row of it; this chunk inside it
+        const unsigned tilepitch = (c.ps4 >> 6) * BLKB, rowpitch = tilepitch * (unsigned)(p.v_wg >> 3);
+        const unsigned soff = (c.soff >> 6) * BLKB;
+        const unsigned tbase = (unsigned)(c.ox0 / C::TWPX) * tilepitch;
 #pragma unroll
         for (int k = 0; k < NVU; ++k) {
             const int u = k * C::NTHREADS + wid * 64 + tl;
-            const int pl = u / C::NSLOT, sl = u - pl * C::NSLOT;
-            // rows outside the image fall outside the descriptor (a negative row wraps beyond 2 GiB); the groups of a tile always exist (v_wg % 8 == 0)
-            const unsigned voff = (unsigned)((c.oy0 - 1 + (sl >> 3)) * (int)rowpitch) + (unsigned)pl * plane_b + (unsigned)(g0 + (sl & 7)) * 16u;
+            const int pl = u / C::NSLOT, sl = u - pl * C::NSLOT, g = sl & 7;
+            // the two values of a row that need a pixel of the neighbouring tile come from the block's edge line
+            const unsigned inblk = ((pl >> 2) == 0 && g == 0) ? (unsigned)(A * 512 + (pl & 3) * 16) : ((pl >> 2) == A - 1 && g == 7) ? (unsigned)(A * 512 + 64 + (pl & 3) * 16)
+                                                                                                                                    : (unsigned)(pl * 8 + g) * 16u;
+            // rows outside the image fall outside the descriptor (a negative row wraps beyond 2 GiB)
+            const unsigned voff = (unsigned)((c.oy0 - 1 + (sl >> 3)) * (int)rowpitch) + tbase + inblk;
             rawv[SET][k] = buf_load4(c.rs, (VU % C::NTHREADS == 0 || u < VU) ? voff : BSVD_WX_OOB, soff);
         }
     };
@@ -760,6 +774,95 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
                 }
             }
             __syncthreads();
+            if constexpr (YV) {
+            [&]() __attribute__((always_inline)) {
+            static_assert(!YV || EPI == BSVD_EPI_PLAIN || true, "");
+            if (part >= C::NPART || (BSVD_WX_ABL & 4)) return;
+            // one finisher wave per (block, half of the MFMA tile's rows): sidx = part, part + NPART, ..
+#pragma unroll
+            for (int s0 = 0; s0 < 2; s0 += C::NPART) {
+                const int sidx = s0 + (C::NPART == 2 ? part : 0);
+                const int m = (lane + 64 * sidx) >> 2, g = m & 7;
+                float mv[A][8];
+#pragma unroll
+                for (int x = 0; x < A; ++x) {
+                    const unsigned char *base = xch + (blk * A + x) * 4096;
+                    const int slot = ((q & 1) * 32 + m) ^ (8 * (q & 1) + 4 * (q >> 1));
+                    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(base + (2 * (q >> 1)) * 1024 + slot * 16);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4 *>(base + (2 * (q >> 1) + 1) * 1024 + slot * 16);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { mv[x][k] = v0[k]; mv[x][4 + k] = v1[k]; }
+                }
+                const int oy = oy0 + 4 * (C::MTL * rnd + mtl) + (m >> 3);
+                const int oxg = ox0 + M * g;
+                // d[1 .. M]: the group's pixels (bias, activation; zero beyond the image: the reader's zero padding); d[0], d[M + 1]: the neighbours'
+                float d[A][8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float mm[A], oo[M];
+#pragma unroll
+                    for (int x = 0; x < A; ++x) mm[x] = mv[x][k];
+                    F::output(mm, oo);
+#pragma unroll
+                    for (int j = 0; j < M; ++j) {
+                        float v = oo[j] + (k < 4 ? bq0[k] : bq1[k - 4]);
+                        if constexpr (ACT == BSVD_ACT_RELU6) v = __builtin_amdgcn_fmed3f(v, 0.f, 6.f);
+                        else if constexpr (ACT == BSVD_ACT_RELU) v = fmaxf(v, 0.f);
+                        d[1 + j][k] = oxg + j < p.Wo ? v : 0.f;
+                    }
+                }
+                // the last pixel of the group to the left, the first of the group to the right: lanes -4 / +4 (same row of the MFMA tile; a tile's
+                // first / last group takes 0 here and is completed by the patch pass)
+                const int la = ((lane - 4) & 63) * 4, ra = ((lane + 4) & 63) * 4;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float l = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(la, __builtin_bit_cast(int, d[M][k])));
+                    const float r = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(ra, __builtin_bit_cast(int, d[1][k])));
+                    d[0][k] = g > 0 ? l : 0.f;
+                    d[A - 1][k] = g < 7 ? r : 0.f;
+                }
+                const bool live = oy < p.Ho && n8 < p.Cout;
+                float *const fbase = p.y + (int64_t)f * p.y_fs;
+                // edge record of the tile: [row][tile x][0: partial of position 0, 1: partial of position A - 1, 2: first column, 3: last column][Cout]
+                constexpr int BLK = v_block_floats(M);
+                float *const erow = fbase + (int64_t)p.Ho * p.ntx * (p.Cout >> 4) * BLK + ((int64_t)(oy * p.ntx + ox0 / C::TWPX) * 4) * p.Cout + n8;
+                float vv[A][8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float din[A], vout[A];
+#pragma unroll
+                    for (int x = 0; x < A; ++x) din[x] = d[x][k];
+                    F::input(din, vout);
+#pragma unroll
+                    for (int x = 0; x < A; ++x) vv[x][k] = vout[x];
+                }
+                if (live && g == 0 && !(BSVD_WX_ABL & 256)) {
+                    *reinterpret_cast<f32x4 *>(erow) = f32x4{vv[0][0], vv[0][1], vv[0][2], vv[0][3]};
+                    *reinterpret_cast<f32x4 *>(erow + 4) = f32x4{vv[0][4], vv[0][5], vv[0][6], vv[0][7]};
+                    *reinterpret_cast<f32x4 *>(erow + 2 * p.Cout) = f32x4{d[1][0], d[1][1], d[1][2], d[1][3]};
+                    *reinterpret_cast<f32x4 *>(erow + 2 * p.Cout + 4) = f32x4{d[1][4], d[1][5], d[1][6], d[1][7]};
+                }
+                if (live && g == 7 && !(BSVD_WX_ABL & 256)) {
+                    *reinterpret_cast<f32x4 *>(erow + p.Cout) = f32x4{vv[A - 1][0], vv[A - 1][1], vv[A - 1][2], vv[A - 1][3]};
+                    *reinterpret_cast<f32x4 *>(erow + p.Cout + 4) = f32x4{vv[A - 1][4], vv[A - 1][5], vv[A - 1][6], vv[A - 1][7]};
+                    *reinterpret_cast<f32x4 *>(erow + 3 * p.Cout) = f32x4{d[M][0], d[M][1], d[M][2], d[M][3]};
+                    *reinterpret_cast<f32x4 *>(erow + 3 * p.Cout + 4) = f32x4{d[M][4], d[M][5], d[M][6], d[M][7]};
+                }
+                // block (row, tile, chunk): [position][quarter][group] x 16 B
+                float *const vrow = fbase + ((int64_t)(oy * p.ntx + ox0 / C::TWPX) * (p.Cout >> 4) + (n8 >> 4)) * BLK + (((n8 >> 3) & 1) * 8 + g) * 4;
+#pragma unroll
+                for (int x = 0; x < A; ++x) {
+                    unsigned hp[4], lp[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) split_pair(vv[x][2 * c], vv[x][2 * c + 1], hp[c], lp[c], mixk);
+                    if (live && !((BSVD_WX_ABL & 128) && hp[0] != 0x12345678u)) {
+                        *reinterpret_cast<f32x4 *>(vrow + x * 128) = __builtin_bit_cast(f32x4, u32x4_t{hp[0], hp[1], hp[2], hp[3]});
+                        *reinterpret_cast<f32x4 *>(vrow + x * 128 + 64) = __builtin_bit_cast(f32x4, u32x4_t{lp[0], lp[1], lp[2], lp[3]});
+                    }
+                }
+            }
+            }();
+            } else
             [&]() __attribute__((always_inline)) {
             // finish
             if (part >= C::NPART || (BSVD_WX_ABL & 4)) return;
@@ -874,10 +977,10 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
 #endif
 }
 
-template <int M, int NH, int NTW, int MT, bool PERSIST, int XF = 0>
+template <int M, int NH, int NTW, int MT, bool PERSIST, int XF = 0, bool YV = false>
 __global__ __launch_bounds__((XCfg<M, NH, NTW, MT, PERSIST>::NTHREADS), (XCfg<M, NH, NTW, MT, PERSIST>::NW / 4 * XCfg<M, NH, NTW, MT, PERSIST>::WGS)) void winox_kernel(const ConvParams p)
 {
-    winox_tile<M, NH, NTW, MT, PERSIST, XF, XCfg<M, NH, NTW, MT, PERSIST>::TR>(p);
+    winox_tile<M, NH, NTW, MT, PERSIST, XF, XCfg<M, NH, NTW, MT, PERSIST>::TR, 0, YV>(p);
 }
 
 #ifndef BSVD_WX_TAIL
@@ -890,11 +993,11 @@ constexpr bool wx_tail_folds(int m) { return BSVD_WX_TAIL == 2 && m == 2; }
 // 480 x 856): those workgroups run the 8-row body -- the same instruction sequence per output (bit-identical, like the 8-row tile of
 // small grids), 0.57 of a full tile's time for tiles that are <= half alive.  A wave-uniform branch at the very top, two complete
 // bodies: nothing inside the K loops knows about it (the in-loop form, BSVD_WX_DEADROWS, cost every tile its MFMA schedule).
-template <int M, int NH, int NTW, int XF>
+template <int M, int NH, int NTW, int XF, bool YV = false>
 __global__ __launch_bounds__((XCfg<M, NH, NTW, 4, false>::NTHREADS), (XCfg<M, NH, NTW, 4, false>::NW / 4)) void winox_kernel_tail(const ConvParams p)
 {
     // this workgroup's tile, decoded like winox_tile does (XCD-contiguous tile ranges, optional reverse walk)
-    constexpr bool FOLDS = wx_tail_folds(M) && XF != 2;       // (transformed-domain input: the 8-row body for the short band, like F(6,3))
+    constexpr bool FOLDS = wx_tail_folds(M) && XF != 2 && !YV;       // (transformed-domain input / output: the 8-row body for the short band, like F(6,3))
     const WxGrid G = wx_grid(p.nty, p.ntx, p.nct, p.Ho, FOLDS);
     const int ntiles = p.frames * G.per_frame;
     const int bid = blockIdx.x, xcd = bid & 7;
@@ -906,12 +1009,65 @@ __global__ __launch_bounds__((XCfg<M, NH, NTW, 4, false>::NTHREADS), (XCfg<M, NH
         else winox_tile<M, NH, NTW, 4, false, XF, 16, 1>(p);
     } else {
         const int ty = (lid / (p.nct * p.ntx)) % p.nty;
-        if (p.nty >= 2 && p.Ho - ty * 16 <= 8) winox_tile<M, NH, NTW, 2, false, XF, 16>(p);
-        else winox_tile<M, NH, NTW, 4, false, XF, 16>(p);
+        if (p.nty >= 2 && p.Ho - ty * 16 <= 8) winox_tile<M, NH, NTW, 2, false, XF, 16, 0, YV>(p);
+        else winox_tile<M, NH, NTW, 4, false, XF, 16, 0, YV>(p);
     }
 }
 
-template <int M, int NH, int NTW, int MT = 4, bool PERSIST = false, int XF = 0>
+// The patch pass behind a y_v launch: position 0 of a tile's first group and position A - 1 of its last group need one pixel of the
+// neighbouring tile -- BT[0][0] * (last column of the tile to the left), BT[A - 1][A - 1] * (first column of the tile to the right).  One
+// thread per (frame, row, tile, side, 8 channels): partial sum + coefficient x the neighbour's edge column (0 at the image border) from the frame's
+// edge record, split, into the block's EDGE LINE (dense 16-byte writes: a block's line is filled by four threads).  Readers take these two
+// values from the edge line only; what the producer left in the planes at those two slots is never read.
+template <int M>
+__global__ void v_patch_kernel(float *__restrict__ y, int64_t y_fs, int frames, int Ho, int Cout, int ntx)
+{
+    constexpr int A = M + 2, BLK = v_block_floats(M);
+    using F = WinoForm<M>;
+    fp16_saturate_on();
+    const int c8n = Cout >> 3;
+    const int64_t total = (int64_t)frames * Ho * ntx * 2 * c8n;
+    const float cl = (float)F::BT[0][0], cr = (float)F::BT[A - 1][A - 1];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % c8n);
+        int64_t r = i / c8n;
+        const int side = (int)(r & 1); r >>= 1;
+        const int t = (int)(r % ntx); r /= ntx;
+        const int row = (int)(r % Ho);
+        const int f = (int)(r / Ho);
+        float *const fbase = y + f * y_fs;
+        const float *const e = fbase + (int64_t)Ho * ntx * (Cout >> 4) * BLK + ((int64_t)row * ntx * 4) * Cout + c8 * 8;
+        // side 0: partial (record 0 of tile t) + cl * last column of tile t - 1 (record 3); side 1: partial (record 1) + cr * first column of tile t + 1 (record 2)
+        const float *const part = e + (int64_t)(t * 4 + side) * Cout;
+        const int tn = side ? t + 1 : t - 1;
+        const bool has = tn >= 0 && tn < ntx;
+        const float *const pix = e + (int64_t)((has ? tn : t) * 4 + (side ? 2 : 3)) * Cout;
+        const float c = side ? cr : cl;
+        _Float16 hi[8], lo[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = has ? __builtin_fmaf(c, pix[k], part[k]) : part[k];
+            hi[k] = (_Float16)v;
+            lo[k] = (_Float16)__builtin_fmaf((float)hi[k], -1.0f, v);
+        }
+        float *const dst = fbase + ((int64_t)(row * ntx + t) * (Cout >> 4) + (c8 >> 1)) * BLK + A * 128 + (side * 4 + (c8 & 1)) * 4;
+        *reinterpret_cast<f32x4 *>(dst) = *reinterpret_cast<const f32x4 *>(hi);
+        *reinterpret_cast<f32x4 *>(dst + 8) = *reinterpret_cast<const f32x4 *>(lo);
+    }
+}
+
+template <int M>
+static int launch_v_patch(const ConvParams &p, hipStream_t stream)
+{
+    const int ntx = (p.Wo + 8 * M - 1) / (8 * M);
+    const int64_t total = (int64_t)p.frames * p.Ho * ntx * 2 * (p.Cout >> 3);
+    int64_t grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(v_patch_kernel<M>, dim3((unsigned)grid), dim3(256), 0, stream, p.y, p.y_fs, p.frames, p.Ho, p.Cout, ntx);
+    return (int)hipGetLastError();
+}
+
+template <int M, int NH, int NTW, int MT = 4, bool PERSIST = false, int XF = 0, bool YV = false>
 static int launch_winox_cfg(const ConvParams &pin, hipStream_t stream, char *name, int name_len, int max_wgs = BSVD_CUS)
 {
     using C = XCfg<M, NH, NTW, MT, PERSIST>;
@@ -924,8 +1080,15 @@ static int launch_winox_cfg(const ConvParams &pin, hipStream_t stream, char *nam
     } else if constexpr (XF == 0) {
         if (pin.x_f32 || pin.x_v) { set_error("bsvd_conv3x3: x_f32 / x_v are not available for this Winograd variant"); return -19; }
     }
+    // transformed-domain OUTPUT: the product's F(6,3) configuration (its tile grid never folds; the epilogue's pixel groups are the reader's)
+    if constexpr (!YV) {
+        if (pin.y_v) {
+            if constexpr (!PERSIST && C::NTHREADS == 512 && M == 6) return launch_winox_cfg<M, NH, NTW, MT, PERSIST, XF, true>(pin, stream, name, name_len, max_wgs);
+            else { set_error("bsvd_conv3x3: y_v is not available for this Winograd variant (F(6,3) only)"); return -19; }
+        }
+    }
     if (name) {
-        snprintf(name, name_len, "winox_kernel<F(%d,3),%dx%d>[f16x3]%s%s%s", M, NH, NTW, MT == 2 ? "[8 rows]" : "", PERSIST ? "[persistent]" : "", XF == 2 ? "[V in]" : XF ? "[f32 in]" : "");
+        snprintf(name, name_len, "winox_kernel<F(%d,3),%dx%d>[f16x3]%s%s%s%s", M, NH, NTW, MT == 2 ? "[8 rows]" : "", PERSIST ? "[persistent]" : "", XF == 2 ? "[V in]" : XF ? "[f32 in]" : "", YV ? "[V out]" : "");
         return 0;
     }
     ConvParams p = pin;
@@ -933,25 +1096,26 @@ static int launch_winox_cfg(const ConvParams &pin, hipStream_t stream, char *nam
     p.nty = (p.Ho + C::TR - 1) / C::TR;
     p.nct = (p.Cout + C::BN - 1) / C::BN;
     constexpr bool TAILK = BSVD_WX_TAIL && MT == 4 && !PERSIST && C::NTHREADS == 512 && (M == 2 || M == 6);
-    const int64_t nblk = (int64_t)p.frames * wx_grid(p.nty, p.ntx, p.nct, p.Ho, TAILK && wx_tail_folds(M) && XF != 2).per_frame;
+    const int64_t nblk = (int64_t)p.frames * wx_grid(p.nty, p.ntx, p.nct, p.Ho, TAILK && wx_tail_folds(M) && XF != 2 && !YV).per_frame;
     if (nblk <= 0 || nblk > 0x7fffffff) { set_error("bsvd_conv3x3: grid of %lld workgroups", (long long)nblk); return -1; }
     // the product's 16-row tile launches are ALL this kernel (one symbol per form in a profile): a grid without such a band never takes
     // the branch
     if constexpr (TAILK) {
-        static_assert(XCfg<M, NH, NTW, 4, false, wx_tail_folds(M) && XF != 2>::LDS_BYTES == C::LDS_BYTES, "the folded tile's transform buffers fit under the exchange");
+        static_assert(XCfg<M, NH, NTW, 4, false, wx_tail_folds(M) && XF != 2 && !YV>::LDS_BYTES == C::LDS_BYTES, "the folded tile's transform buffers fit under the exchange");
         static std::atomic<int> granted_t[MAX_DEVICES];
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&winox_kernel_tail<M, NH, NTW, XF>), C::LDS_BYTES, granted_t);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&winox_kernel_tail<M, NH, NTW, XF, YV>), C::LDS_BYTES, granted_t);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((winox_kernel_tail<M, NH, NTW, XF>), dim3((unsigned)nblk), dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
-        return (int)hipGetLastError();
+        hipLaunchKernelGGL((winox_kernel_tail<M, NH, NTW, XF, YV>), dim3((unsigned)nblk), dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
     } else {
         static std::atomic<int> granted[MAX_DEVICES];
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&winox_kernel<M, NH, NTW, MT, PERSIST, XF>), C::LDS_BYTES, granted);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&winox_kernel<M, NH, NTW, MT, PERSIST, XF, YV>), C::LDS_BYTES, granted);
         if (e != hipSuccess) return (int)e;
         const unsigned grid = PERSIST && nblk > max_wgs ? (unsigned)max_wgs : (unsigned)nblk;
-        hipLaunchKernelGGL((winox_kernel<M, NH, NTW, MT, PERSIST, XF>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
-        return (int)hipGetLastError();
+        hipLaunchKernelGGL((winox_kernel<M, NH, NTW, MT, PERSIST, XF, YV>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
     }
+    const int rc = (int)hipGetLastError();
+    if constexpr (YV && !(BSVD_WX_ABL & 512)) { if (rc == 0) return launch_v_patch<M>(p, stream); }
+    return rc;
 }
 
 // Which wino_m codes this build runs.  Product: 2 / 6 (F(2,3) / F(6,3), each picking the half-height tile for grids that do not fill the

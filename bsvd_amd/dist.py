@@ -61,14 +61,16 @@ class HaloExchanger:
         has_left, has_right = self.rank > 0, self.rank + 1 < self.world
         if fold == 0 or not (has_left or has_right):
             return _Pending([], None, None)
-        H, W = v.shape[1:3]
+        mk = getattr(self.ex, "empty_halo", None) or (lambda t, n: torch.empty(tuple(t.shape[1:3]) + (n,), dtype=t.dtype, device=t.device))
+        raw = lambda t: getattr(t, "t", t) if not isinstance(t, torch.Tensor) else t      # the torch tensor behind a transformed slice
         ops, recv_prev, recv_next, staged, keep = [], None, None, [], []
         stage = self.host_staging and v.is_cuda
 
         def wire(t, receiving):
             """tensor handed to the backend: the device buffer itself, or a host mirror when staging"""
             if not stage:
-                return t
+                return raw(t)
+            t = raw(t)
             h = torch.empty(t.shape, dtype=t.dtype, device="cpu") if receiving else t.cpu()
             if receiving:
                 staged.append((h, t))
@@ -76,17 +78,17 @@ class HaloExchanger:
 
         if has_right:
             send_last = self.ex.halo_pack(v[-1], fold, fold)          # my last frame's [fold:2fold] -> right's halo_prev
-            recv_next = torch.empty((H, W, fold), dtype=v.dtype, device=v.device)
+            recv_next = mk(v, fold)
             ops += [dist.P2POp(dist.isend, wire(send_last, False), self._peer(self.rank + 1), self.group),
                     dist.P2POp(dist.irecv, wire(recv_next, True), self._peer(self.rank + 1), self.group)]
-            self.bytes_sent += send_last.numel() * send_last.element_size()
+            self.bytes_sent += raw(send_last).numel() * 4
             keep.append(send_last)
         if has_left:
             send_first = self.ex.halo_pack(v[0], 0, fold)             # my first frame's [0:fold] -> left's halo_next
-            recv_prev = torch.empty((H, W, fold), dtype=v.dtype, device=v.device)
+            recv_prev = mk(v, fold)
             ops += [dist.P2POp(dist.isend, wire(send_first, False), self._peer(self.rank - 1), self.group),
                     dist.P2POp(dist.irecv, wire(recv_prev, True), self._peer(self.rank - 1), self.group)]
-            self.bytes_sent += send_first.numel() * send_first.element_size()
+            self.bytes_sent += raw(send_first).numel() * 4
             keep.append(send_first)
         reqs = dist.batch_isend_irecv(ops)
         self.exchanges += 1

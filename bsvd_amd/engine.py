@@ -82,6 +82,76 @@ F32_HANDOVER_DEFAULT = True
 _SOLE_CONSUMER = {"down0": "d0c1", "d0c1": "d0c2", "down1": "d1c1", "d1c1": "d1c2", "d1c2": "u2c1", "u2c1": "u2c2", "u2c2": "up2",
                   "up2": "u1c1", "u1c1": "u1c2", "u1c2": "up1"}
 
+# Transformed-domain hand-over (BsvdConvArgs.y_v / x_v, ABI v11): where producer AND sole consumer run F(6,3), the producer's
+# epilogue applies the consumer's input transform once and stores the tensor as V planes; the consumer's K loop is a 16-byte copy.  Takes
+# precedence over the plain-fp32 hand-over for the pairs it covers (the others -- stride-2 and PixelShuffle producers -- keep fp32).
+V_HANDOVER_DEFAULT = False
+V_FORM = 6              # the form whose epilogue writes V (conv3x3_winox.hip: launch_winox_cfg)
+
+
+class VT:
+    """A transformed-domain activation tensor.  LOGICAL shape [T, H, W, C] (what the schedules reason about: frames, slicing, halos);
+    storage ``t`` = [T, bsvd_v_frame_elems(H, W, C, m)] fp32 (V planes + edge record per frame, include/bsvd_hip.h).  Quacks like the
+    torch tensors the schedules pass around as far as they look: shape, frame indexing / slicing, data_ptr, device, dtype."""
+    __slots__ = ("t", "H", "W", "C", "m")
+
+    def __init__(self, t, H, W, C, m):
+        self.t, self.H, self.W, self.C, self.m = t, int(H), int(W), int(C), int(m)
+
+    @staticmethod
+    def frame_elems(H, W, C, m):
+        n = _lib.load().bsvd_v_frame_elems(H, W, C, m)
+        if n <= 0:
+            raise ValueError("bsvd_v_frame_elems(%d, %d, %d, %d)" % (H, W, C, m))
+        return int(n)
+
+    @classmethod
+    def empty(cls, T, H, W, C, m, device):
+        return cls(torch.empty((T, cls.frame_elems(H, W, C, m)), dtype=torch.float32, device=device), H, W, C, m)
+
+    @property
+    def shape(self):
+        return ((self.t.shape[0],) if self.t.dim() == 2 else ()) + (self.H, self.W, self.C)
+
+    def __getitem__(self, idx):
+        if self.t.dim() != 2:
+            raise IndexError("a single transformed frame cannot be indexed")
+        return VT(self.t[idx], self.H, self.W, self.C, self.m)
+
+    def __len__(self):
+        return self.t.shape[0]
+
+    @property
+    def frame_stride(self):
+        return self.t.stride(0) if self.t.dim() == 2 else self.t.numel()
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+    def is_contiguous(self):
+        return self.t.is_contiguous()
+
+    def fill_(self, v):
+        self.t.fill_(v)
+        return self
+
+    def numel(self):
+        return self.t.numel()
+
+    device = property(lambda self: self.t.device)
+    dtype = property(lambda self: self.t.dtype)
+    is_cuda = property(lambda self: self.t.is_cuda)
+
+    def blocks(self):
+        """[.., H, tiles, C / 16, block floats] view of the frame's blocks (include/bsvd_hip.h: (m + 2) x 4 x 8 units of 16 B + the edge
+        line per (row, tile of 8 groups, 16-channel chunk)), without the producer's edge record behind them"""
+        ntx = _lib.load().bsvd_v_groups(self.W, self.m) // 8
+        blk = ((self.m + 2) * 32 + 8) * 4
+        n = self.H * ntx * (self.C // 16) * blk
+        v = self.t[..., :n]
+        return v.reshape(*v.shape[:-1], self.H, ntx, self.C // 16, blk)
+
+
 WINO_MIN_CIN = 128     # narrowest layer the Winograd form takes (engine.PackedNet(wino_min_cin=...))
 
 
@@ -98,7 +168,8 @@ class PackedNet:
     """Device-resident pre-packed weights of every layer (one-time transform of the state_dict,
     cf. BSVD.load, bsvd_arch.py:462-474): {spec.key: (w_packed, bias_packed)}."""
 
-    def __init__(self, net, state, device, precision="fp32", wide_conv="direct", wino_min_cin=None, fuse_pairs=False, f32_handover=None):
+    def __init__(self, net, state, device, precision="fp32", wide_conv="direct", wino_min_cin=None, fuse_pairs=False, f32_handover=None,
+                 v_handover=None):
         lib = require_hip()
         if not wide_conv_known(wide_conv, lib):
             if wide_conv in MEASURE_WIDE_CONV:
@@ -176,18 +247,28 @@ class PackedNet:
                 self.head[sp3.key] = (hw, hb, sp0)
             # plain-fp32 hand-over: producer -> consumer pairs whose consumer runs a product Winograd form and whose producer can store fp32
             # (a Winograd-form layer, or a PLAIN direct-form split layer: the stride-2 convs).  Decided from the layer forms alone.
+            # ... and the transformed-domain hand-over (BsvdConvArgs.y_v / x_v) where producer and consumer both run F(6,3) and the producer is a
+            # PLAIN layer: {producer key: m}, {consumer key: m}.  It takes precedence over the fp32 hand-over for those pairs.
             self.f32_out, self.f32_in = set(), set()
-            if (F32_HANDOVER_DEFAULT if f32_handover is None else f32_handover) and precision == "f16x3":
-                for blk in (getattr(net, "temp1", None), getattr(net, "temp2", None)):
-                    if blk is None:
-                        continue
-                    for pn, cn in _SOLE_CONSUMER.items():
-                        if pn in blk and cn in blk:
-                            pr, co = blk[pn], blk[cn]
-                            if self.wino_layer_abi.get(co.key) in (2, 6) and pr.out_channels_pad == co.cin_pad and \
-                                    (pr.key in self.wino or (pr.epilogue == EPI_PLAIN and pr.key not in edge)):
-                                self.f32_out.add(pr.key)
-                                self.f32_in.add(co.key)
+            self.v_out, self.v_in = {}, {}
+            f32 = (F32_HANDOVER_DEFAULT if f32_handover is None else f32_handover) and precision == "f16x3"
+            vh = (V_HANDOVER_DEFAULT if v_handover is None else v_handover) and precision == "f16x3"
+            for blk in (getattr(net, "temp1", None), getattr(net, "temp2", None)):
+                if blk is None:
+                    continue
+                for pn, cn in _SOLE_CONSUMER.items():
+                    if pn in blk and cn in blk:
+                        pr, co = blk[pn], blk[cn]
+                        if pr.out_channels_pad != co.cin_pad:
+                            continue
+                        if vh and self.wino_layer_abi.get(co.key) == V_FORM and self.wino_layer_abi.get(pr.key) == V_FORM and \
+                                pr.epilogue == EPI_PLAIN and pr.stride == 1:
+                            self.v_out[pr.key] = V_FORM
+                            self.v_in[co.key] = V_FORM
+                        elif f32 and self.wino_layer_abi.get(co.key) in (2, 6) and \
+                                (pr.key in self.wino or (pr.epilogue == EPI_PLAIN and pr.key not in edge)):
+                            self.f32_out.add(pr.key)
+                            self.f32_in.add(co.key)
             # fused 64-channel pairs (BsvdConvArgs.pre_w_packed), keyed by the SECOND conv: both layers keep their ordinary packs (the
             # first conv's is handed over as pre_w_packed / pre_bias), so a fused and an unfused launch read the same weights
             self.pairs = {}
@@ -241,6 +322,7 @@ class HipExecutor:
         # host side of the ABI, once per executor -- the library itself reads no environment
         self.fat_min_wgs = int(os.environ.get("BSVD_FAT_MIN_WGS", "0") or 0)
         self.force_x_f32 = self.force_y_f32 = None      # tests: override the pack's plain-fp32 hand-over decision for single layers
+        self.force_y_v = None                           # tests: 0 / m -- override the pack's transformed-domain output decision
         self.record_variants = False     # profiling aid: ask the library which kernel instantiation each conv uses
         self.last_variant = None
 
@@ -271,6 +353,17 @@ class HipExecutor:
 
     def halo_pack(self, frame, c0, n):
         """compact [H,W,n] copy of channels [c0,c0+n) of one NHWC frame [H,W,C] (message to a neighbour shard)"""
+        if isinstance(frame, VT):        # transformed frame: the chunks of channels [c0, c0 + n) of every row = a transformed frame of n channels
+            if c0 % 16 or n % 16:
+                raise ValueError("halo_pack: a transformed tensor is cut in whole 16-channel chunks")
+            if frame.t.dim() == 2:
+                if len(frame) != 1:
+                    raise ValueError("halo_pack: one frame")
+                frame = frame[0]
+            out = VT.empty(1, frame.H, frame.W, n, frame.m, frame.device)[0]
+            out.blocks().copy_(frame.blocks()[:, :, c0 // 16:(c0 + n) // 16])
+            self.launches += 1
+            return out
         H, W, C = frame.shape[-3:]
         out = torch.empty((H, W, n), dtype=torch.float32, device=frame.device)
         # split16: whole 16-channel chunks are plain float ranges; an 8-channel half chunk (fold 8) is two pieces
@@ -282,6 +375,12 @@ class HipExecutor:
 
     def halo_unpack(self, slice_, frame, c0):
         """scatter a compact [H,W,n] slice into channels [c0,c0+n) of the NHWC frame [H,W,C] (in place)"""
+        if isinstance(frame, VT) or isinstance(slice_, VT):
+            if not (isinstance(frame, VT) and isinstance(slice_, VT)) or c0 % 16 or slice_.C % 16:
+                raise ValueError("halo_unpack: a transformed slice goes into a transformed frame, in whole 16-channel chunks")
+            frame.blocks()[..., c0 // 16:(c0 + slice_.C) // 16, :].copy_(slice_.blocks())
+            self.launches += 1
+            return frame
         H, W, C = frame.shape[-3:]
         n = slice_.shape[-1]
         if not (frame.is_contiguous() and slice_.is_contiguous()):
@@ -293,12 +392,34 @@ class HipExecutor:
         return frame
 
     def out_shape(self, sp, x):
-        """Shape of the NHWC tensor layer ``sp`` produces from NHWC input ``x``."""
+        """(Logical) shape of the NHWC tensor layer ``sp`` produces from NHWC input ``x``."""
         T, H, W, _ = x.shape
         Ho, Wo = (H - 1) // sp.stride + 1, (W - 1) // sp.stride + 1
         if sp.epilogue == EPI_PS_ADD:
             return (T, 2 * Ho, 2 * Wo, sp.cout_pad // 4)
         return (T, Ho, Wo, sp.cout_pad)
+
+    def out_v(self, sp):
+        """m if layer ``sp`` writes its output in the transformed domain (PackedNet.v_out), else 0"""
+        if self.force_y_v is not None:
+            return self.force_y_v
+        return getattr(self.packed, "v_out", {}).get(sp.key, 0)
+
+    def empty_out(self, sp, x, frames=None):
+        """Uninitialised output tensor of layer ``sp`` for input ``x`` -- a torch tensor, or a VT where the layer writes the transformed domain"""
+        shape = self.out_shape(sp, x)
+        if frames is not None:
+            shape = (frames,) + tuple(shape[1:])
+        m = self.out_v(sp)
+        if m:
+            return VT.empty(shape[0], shape[1], shape[2], shape[3], m, x.device)
+        return torch.empty(shape, dtype=torch.float32, device=x.device)
+
+    def empty_halo(self, v, n):
+        """receive buffer for an n-channel temporal halo slice of (a frame of) ``v``"""
+        if isinstance(v, VT):
+            return VT.empty(1, v.H, v.W, n, v.m, v.device)[0]
+        return torch.empty(tuple(v.shape[-3:-1]) + (n,), dtype=torch.float32, device=v.device)
 
     # -- the fused layer -------------------------------------------------------------------------
     planar_io = True      # the edge kernels read planar NCHW input / write planar NCHW output directly
@@ -395,7 +516,14 @@ class HipExecutor:
             T, H, W, cin_pad = x.shape
             if cin_pad != sp.cin_pad:
                 raise ValueError("%s: input has %d channels, layer expects %d" % (sp.key, cin_pad, sp.cin_pad))
-            a.x_frame_stride = H * W * cin_pad
+            a.x_frame_stride = x.frame_stride if isinstance(x, VT) else H * W * cin_pad
+        xv = x.m if isinstance(x, VT) else 0
+        if xv != getattr(self.packed, "v_in", {}).get(sp.key, 0) and self.force_y_v is None:
+            raise ValueError("%s: the pack expects a %s input, got a %s one" % (sp.key, "transformed-domain" if not xv else "pixel-domain",
+                                                                               "transformed-domain" if xv else "pixel-domain"))
+        for nm, h in (("halo_prev", halo_prev), ("halo_next", halo_next)):
+            if h is not None and isinstance(h.t, VT) != bool(xv):
+                raise ValueError("%s: %s and the input must live in the same domain" % (sp.key, nm))
         Ho, Wo = (H - 1) // sp.stride + 1, (W - 1) // sp.stride + 1
         if y_planar is not None:
             yc, clamp = y_planar
@@ -409,14 +537,17 @@ class HipExecutor:
             yshape = (T, 2 * Ho, 2 * Wo, sp.cout_pad // 4)
         else:
             yshape = (T, Ho, Wo, sp.cout_pad)
+        yv = self.out_v(sp) if (y_planar is None and pre is None and head is None) else 0
         if out is not None:
-            if tuple(out.shape) != yshape or not out.is_contiguous() or out.dtype != torch.float32:
-                raise ValueError("%s: out has shape %s, expected contiguous %s" % (sp.key, tuple(out.shape), yshape))
+            if tuple(out.shape) != yshape or not out.is_contiguous() or out.dtype != torch.float32 or (out.m if isinstance(out, VT) else 0) != yv:
+                raise ValueError("%s: out has shape %s, expected contiguous %s%s" % (sp.key, tuple(out.shape), yshape, " in the transformed domain" if yv else ""))
             y = out
         elif alloc:
-            y = torch.empty(yshape, dtype=torch.float32, device=x.device)
+            y = VT.empty(yshape[0], yshape[1], yshape[2], yshape[3], yv, x.device) if yv else torch.empty(yshape, dtype=torch.float32, device=x.device)
         else:
             y = None
+            if yv:
+                raise ValueError("%s: a transformed-domain output needs its tensor" % sp.key)
         wp, bp = self.packed.tensors[sp.key]
         a.x = x.data_ptr()
         if sp.tsm:
@@ -428,10 +559,11 @@ class HipExecutor:
         a.bias_packed = bp.data_ptr()
         yf = self.force_y_f32 if self.force_y_f32 is not None else sp.key in getattr(self.packed, "f32_out", ())
         xf = self.force_x_f32 if self.force_x_f32 is not None else sp.key in getattr(self.packed, "f32_in", ())
-        if yf:
+        if yf and not yv:
             a.y_f32 = 1
-        if xf and wp is None:
+        if xf and wp is None and not xv:
             a.x_f32 = 1
+        a.x_v, a.y_v = xv, yv
         if wp is not None:
             a.w_packed = wp.data_ptr()
         else:
@@ -442,9 +574,9 @@ class HipExecutor:
                     if h.t.data_ptr() % 16 or h.pstride % 4 or h.coff % 4:
                         raise ValueError("%s: the Winograd form needs a 16-byte aligned %s (pointer %% 16, pstride %% 4, coff %% 4 elements); "
                                          "got pstride %d, coff %d" % (sp.key, nm, h.pstride, h.coff))
-                    if H * W * h.pstride * 4 >= 2 ** 31 - 1:
-                        raise ValueError("%s: %s spans H*W*pstride*4 = %d bytes >= 2 GiB (32-bit byte offsets inside one frame)"
-                                         % (sp.key, nm, H * W * h.pstride * 4))
+                    span = (H * (self.lib.bsvd_v_groups(W, xv) // 8) * (((xv + 2) * 32 + 8) // 16) if xv else H * W) * h.pstride * 4
+                    if span >= 2 ** 31 - 1:
+                        raise ValueError("%s: %s spans %d bytes >= 2 GiB (32-bit byte offsets inside one frame)" % (sp.key, nm, span))
             if x.data_ptr() % 16:
                 raise ValueError("%s: the Winograd form needs a 16-byte aligned input" % sp.key)
             a.w_wino_packed, a.wino_m = self.packed.wino[sp.key].data_ptr(), self.packed.wino_layer_abi[sp.key]
@@ -464,6 +596,8 @@ class HipExecutor:
         a.y_frame_stride = 1
         for d in yshape[1:]:
             a.y_frame_stride *= d
+        if yv:
+            a.y_frame_stride = y.frame_stride
         a.frames, a.H, a.W = T, H, W
         a.Cin, a.Cout = sp.cin_pad, sp.cout_pad
         a.stride = sp.stride

@@ -83,7 +83,8 @@ def denblock_clip(ex, S, x, halo_fn=None, x_planar=False, y_planar=None):
             # interior frames -- whose temporal neighbours are all local -- are convolved; the two boundary
             # frames follow once the neighbours' slices have arrived.
             pending = halo_fn.start(sp, v)
-            y = v.new_empty(ex.out_shape(sp, v))
+            mk = getattr(ex, "empty_out", None)
+            y = mk(sp, v) if mk else v.new_empty(ex.out_shape(sp, v))
             ex.conv(sp, v[1:-1], halo_prev=Halo(v[0], C, sp.fold), halo_next=Halo(v[-1], C, 0), out=y[1:-1])
             hp, hn = pending.finish()
             ex.conv(sp, v[0:1], halo_prev=hp, halo_next=Halo(v[1], C, 0), out=y[0:1])

@@ -49,8 +49,9 @@ def ring_depth(name, is_handover=False, is_exit=False):
     return min(d for d in _DEPTHS if d >= need)
 
 
-def ring_bytes_estimate(net, H, W, chunk=1):
-    """Device bytes StreamEngine(net, ..., H, W, chunk) allocates for its rings (fp32 words; split16 is the same size)."""
+def ring_bytes_estimate(net, H, W, chunk=1, v_keys=()):
+    """Device bytes StreamEngine(net, ..., H, W, chunk) allocates for its rings (fp32 words; split16 is the same size; the layers in
+    ``v_keys`` write the transformed domain: (m + 2) / m = 4 / 3 of the pixels' bytes for F(6,3), group padding and the edge record on top)."""
     total = 10 * chunk * net.net_in_ch * H * W
     for blk in (net.temp1, net.temp2):
         h, w = H, W
@@ -63,6 +64,8 @@ def ring_bytes_estimate(net, H, W, chunk=1):
             exit_ = blk is net.temp2 and name == "out3"
             if exit_:
                 n = sp.cout * ho * wo
+            if sp.key in v_keys:
+                n = int(n * 1.45)
             total += n * chunk * ring_depth(name, blk is net.temp1 and name == "out3", exit_)
     return 4 * total
 
@@ -154,12 +157,18 @@ class StreamEngine:
         self.ring_bytes = 0
         n = self.chunk
 
-        def ring(key, shape, depth):
-            buf = alloc((depth,) + tuple(shape))
+        out_v = getattr(ex, "out_v", None)
+
+        def ring(key, shape, depth, vm=0):
+            if vm:                    # a layer that writes the transformed domain (engine.VT): [n, H, W, C] logical, its own frame size
+                from .engine import VT
+                buf = alloc((depth, shape[0], VT.frame_elems(shape[1], shape[2], shape[3], vm)))
+            else:
+                buf = alloc((depth,) + tuple(shape))
             if poison:                # tests: a slot read before it was written shows up as NaN
                 buf.fill_(float("nan"))
             self.ring_bytes += buf.numel() * 4
-            self.rings[key] = [buf[i] for i in range(depth)]
+            self.rings[key] = [VT(buf[i], shape[1], shape[2], shape[3], vm) if vm else buf[i] for i in range(depth)]
 
         # the caller's frames are copied (and converted to fp32) into this ring: inc0 reads them in place, the residual
         # of DenBlock 1 reads them again 8 steps later (MemSkip skip1, bsvd_arch.py:378,394)
@@ -187,7 +196,7 @@ class StreamEngine:
                     shape = (n, sp.cout, ho, wo)
                 if sp.key in fused_away:
                     continue
-                ring(sp.key, shape, ring_depth(name, blk is net.temp1 and name == "out3", sp.key == exit_key))
+                ring(sp.key, shape, ring_depth(name, blk is net.temp1 and name == "out3", sp.key == exit_key), out_v(sp) if out_v else 0)
         self.t1 = _DenBlockStream(net.temp1)
         self.t2 = _DenBlockStream(net.temp2)
         self.r1 = _Recorder(self)

@@ -172,12 +172,15 @@ typedef struct BsvdConvArgs {
      * shares.  With y_v != 0 the producer's epilogue does it ONCE, on the fp32 values it holds anyway, and stores the
      * tensor in the transformed domain; with x_v != 0 the reader's K loop is a plain 16-byte copy into LDS.  Layout of such a tensor, per
      * frame (bsvd_v_frame_elems(H, W, C, m) floats):
-     *     V[row][C / 16 chunks][m + 2 positions][4 quarters: hi c0-7, hi c8-15, lo c0-7, lo c8-15][Wg groups] x 16 bytes,
-     *         Wg = ceil(W / m) rounded up to a multiple of 8 (a group = m consecutive pixels of a row; position xi of group g =
-     *         sum_i BT[xi][i] * d[m g - 1 + i], pixels outside the image = 0), followed by
-     *     E[row][ceil(W / 8m) tiles][4][C] fp32 -- the producer's per-tile edge record (partial sums of the two positions that need a pixel
-     *         of the neighbouring tile + its own first / last pixel column), consumed by the patch pass that bsvd_conv3x3 issues
-     *         right behind a y_v launch on the same stream (one small second kernel: the only cross-tile dependency of the transform).
+     *     B[row][T tiles of 8 groups][C / 16 chunks] blocks of (m + 2) x 512 + 128 bytes (4224 for F(6,3)):
+     *         [m + 2 positions][4 quarters: hi c0-7, hi c8-15, lo c0-7, lo c8-15][8 groups] x 16 bytes -- the reader's LDS planes of one patch row of
+     *         one chunk, contiguous; a group = m consecutive pixels of a row, T = ceil(W / 8m); position xi of group g =
+     *         sum_i BT[xi][i] * d[m g - 1 + i], pixels outside the image = 0 -- followed by the block's EDGE LINE [side 0 | 1][4 quarters] x 16
+     *         bytes: position 0 of the tile's first group (side 0) and position m + 1 of its last group (side 1), the two values of a tile row
+     *         that need a pixel of the NEIGHBOURING tile.  Readers take these two values from the edge line, never from the planes;
+     *     E[row][T][4][C] fp32 behind the blocks -- the producer's edge record (partial sums of those two positions + the tile's own first / last
+     *         pixel column), consumed by the patch pass that bsvd_conv3x3 issues right behind a y_v launch on the same stream (one small
+     *         second kernel that fills the edge lines: the only cross-tile dependency of the transform).
      * x_v / y_v carry the form's m (2, 4 or 6) and must equal wino_m % 10 of the layer (x_v) resp. of the tensor's reader (y_v).
      * x_v: x AND both halos are such tensors -- halo_*_pstride = channels of the holding tensor, halo_*_coff = first channel, both
      * multiples of 16, exactly as for NHWC halos; x_frame_stride = elements between frames (>= bsvd_v_frame_elems).

@@ -75,9 +75,17 @@ for cin, cout, tsm, act, epi, H, W, T in LAYERS:
         _lib.check(lib.bsvd_conv3x3_variant(ctypes.byref(b), buf, 96), "variant")
         name1 = buf.value.decode()
         ms1 = loop(lambda: _lib.check(lib.bsvd_conv3x3(ctypes.byref(b), _stream_ptr()), "conv V in"))
+        ms2 = None
+        if epi == 0 and m == 6:          # ... and with the epilogue writing the transformed domain (producer side of the hand-over, patch pass included)
+            from bsvd_amd.engine import VT
+            yv = VT.empty(T, H, W, cout, m, dev)
+            c, _ = ex.build_args(sp, xf, **kw)
+            c.x, c.x_frame_stride, c.x_f32, c.x_v = v.data_ptr(), vfe, 0, m
+            c.y, c.y_frame_stride, c.y_f32, c.y_v = yv.data_ptr(), yv.frame_stride, 0, m
+            ms2 = loop(lambda: _lib.check(lib.bsvd_conv3x3(ctypes.byref(c), _stream_ptr()), "conv V in V out"))
         d0, d1 = decode(y0), decode(y1)
         flop = 2.0 * cin * cout * 9 * H * W * T
-        print("%d->%d epi %d %dx%d x%d  %-44s %.4f ms (%4.0f TF) | %-40s %.4f ms (%4.0f TF, %+.1f %%) | to_v %.3f ms | max-abs V-in vs f32-in %.2e, equal %s (|y| %.1f)"
-              % (cin, cout, epi, H, W, T, name0, ms0, flop / ms0 / 1e9, name1, ms1, flop / ms1 / 1e9, (ms1 / ms0 - 1) * 100, ms_tv,
+        print("%d->%d epi %d %dx%d x%d  %-44s %.4f ms (%4.0f TF) | %-40s %.4f ms (%4.0f TF, %+.1f %%) | V in + V out %s ms | to_v %.3f ms | max-abs V-in vs f32-in %.2e, equal %s (|y| %.1f)"
+              % (cin, cout, epi, H, W, T, name0, ms0, flop / ms0 / 1e9, name1, ms1, flop / ms1 / 1e9, (ms1 / ms0 - 1) * 100, ("%.4f" % ms2) if ms2 else "-", ms_tv,
                  float((d0 - d1).abs().max()), bool(torch.equal(y0, y1)), float(d0.abs().max())), flush=True)
         del ex, v

@@ -16,8 +16,13 @@ from oracle import bsvd_oracle as O
 ap = argparse.ArgumentParser()
 ap.add_argument("--json", default=None)
 ap.add_argument("--workloads", default="c1,c2,c3")
+ap.add_argument("--wide-conv", default="auto", help="arithmetic form of the wide split-fp16 layers (bsvd_amd.engine.WIDE_CONV)")
+ap.add_argument("--v-handover", default="auto", choices=["auto", "on", "off"])
+ap.add_argument("--frames", default=None, help="frames per workload instead of 10 / 85 / 20, e.g. 10,10,10")
 a = ap.parse_args()
 FRAMES = {"c1": 10, "c2": 85, "c3": 20}
+if a.frames:
+    FRAMES = dict(zip(a.workloads.split(","), (int(v) for v in a.frames.split(","))))
 dev = torch.device("cuda", 0)
 torch.set_num_threads(bench.usable_cores())
 
@@ -36,7 +41,7 @@ for wname in a.workloads.split(","):
     clean = torch.nn.functional.avg_pool2d(clean[0], 5, 1, 2)[None]
     lq = clean + torch.randn(clean.shape, generator=g) * bench.SIGMA
     nm = None if wl["blind"] else torch.full((1, F, 1, h, w), bench.SIGMA)
-    models = {p: bench.build_model(dev, p, wl["blind"]) for p in ("fp32", "f16x3")}
+    models = {p: bench.build_model(dev, p, wl["blind"], a.wide_conv, v_handover={"auto": "auto", "on": True, "off": False}[a.v_handover]) for p in ("fp32", "f16x3")}
     P = {k: v.detach().float().cpu() for k, v in models["fp32"].state_dict().items()}
     cfg = O.default_cfg(act="relu", interm_ch=30, blind=True) if wl["blind"] else O.default_cfg()
     t0 = time.perf_counter()
@@ -44,7 +49,7 @@ for wname in a.workloads.split(","):
         want = O.stream_forward(lq, P, cfg, noise_map=nm)[0]
     t_cpu = time.perf_counter() - t0
     x = (lq if nm is None else torch.cat([lq, nm], dim=2))[0].to(dev)
-    row = {"workload": wname, "clip": [F, x.shape[1], h, w], "oracle_s": t_cpu, "oracle_fps": F / t_cpu,
+    row = {"workload": wname, "wide_conv": models["f16x3"].wide_conv, "clip": [F, x.shape[1], h, w], "oracle_s": t_cpu, "oracle_fps": F / t_cpu,
            "oracle_psnr_db": psnr(want, clean[0]), "output_max": float(want.abs().max())}
     for p, m in models.items():
         with torch.no_grad():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-workgroup timeline of one conv launch from a -DBSVD_TIMELINE build of the library (BSVD_HIP_LIB=...):
 where a tile's time goes (prologue / K loop / epilogue) and how long a CU slot stays empty between two workgroups.
-usage: BSVD_HIP_LIB=build/ab/lib_tl.so python tools/timeline.py [Cin=128] [Cout=128] [H=270] [W=480] [frames=10]"""
+usage: BSVD_HIP_LIB=build/ab/lib_tl.so python tools/timeline.py [Cin=128] [Cout=128] [H=270] [W=480] [frames=10] [stride=1]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -17,13 +17,14 @@ def main():
     H = int(sys.argv[3]) if len(sys.argv) > 3 else 270
     W = int(sys.argv[4]) if len(sys.argv) > 4 else 480
     T = int(sys.argv[5]) if len(sys.argv) > 5 else 10
+    stride = int(sys.argv[6]) if len(sys.argv) > 6 else 1
     dev = torch.device("cuda", 0)
     rs = np.random.RandomState(0)
 
     class Net:
         pass
     pre = ConvSpec("pre", "pre", 4, cin, 1, False, "relu6", 0)
-    sp = ConvSpec("l", "l", cin, cout, 1, False, "relu6", 0)
+    sp = ConvSpec("l", "l", cin, cout, stride, False, "relu6", 0)
     post = ConvSpec("post", "post", cout, 16, 1, False, "none", 0)
     net = Net(); net.layers = [pre, sp, post]
     st = {}
