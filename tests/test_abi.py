@@ -78,6 +78,13 @@ def test_variant_dry_run_reports_dispatch():
     assert variant(Cout=64, H=540, W=960, Cin=64) == (0, "conv3x3_kernel<2,2,4,1,1>[f32]")
     assert variant(stride=2, Cin=64) == (0, "conv3x3_kernel<2,2,2,2,2>[f32]")
     assert variant(dtype=_lib.BSVD_F16X3, fold=12)[0] == -17 and b"fold 12" in lib.bsvd_last_error()
+    # the split stride-2 tile (round 6: 128 px x 32 ch wave tiles) is a plain conv: a temporal shift on it is refused, never read from the wrong frames
+    assert variant(dtype=_lib.BSVD_F16X3, stride=2, Cin=64) == (0, "conv3x3_kernel<4,1,1,4,2>[f16x3]")
+    assert variant(dtype=_lib.BSVD_F16X3, stride=2, Cin=64, fold=16)[0] == -17 and b"plain convs" in lib.bsvd_last_error()
+    # transformed-domain tensors are options of the Winograd form
+    assert variant(dtype=_lib.BSVD_F16X3, x_v=6)[0] == -22 and variant(dtype=_lib.BSVD_F16X3, y_v=6)[0] == -22
+    assert lib.bsvd_v_groups(240, 6) == 40 and lib.bsvd_v_groups(214, 6) == 40 and lib.bsvd_v_groups(50, 2) == 32 and lib.bsvd_v_groups(240, 5) == -1
+    assert lib.bsvd_v_frame_elems(135, 240, 256, 6) == 135 * 5 * 16 * (8 * 32 + 8) * 4 + 135 * 5 * 4 * 256 and lib.bsvd_v_frame_elems(8, 8, 24, 6) == -1
     # a frame of 2 GiB or more cannot be addressed by the split kernel: the error says so (not "fold")
     assert variant(dtype=_lib.BSVD_F16X3, frames=1, H=4320, W=7680, Cin=64, Cout=64)[0] == -17
     assert b"2 GiB" in lib.bsvd_last_error() and b"4320 x 7680" in lib.bsvd_last_error()

@@ -22,13 +22,16 @@ def kernel_key(name):
         return "conv3x3_kernel<%s,%s,%s,%s,%s>%s%s%s%s" % (mt, nt, wm, wn, st, "[f16x3]" if prec == "1" else "[f32]",
                                                           ("[fold8]" if mix == "true" else "") if fast == "true" else "[generic]",
                                                           planar, "[fused entry]" if headf == "true" else "") + ("[fused pair]" if pref == "true" else "")
-    m = re.search(r"winox_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)(?:, (true|false))?>", name)
+    # winox_kernel<M, NH, NTW, MT, PERSIST, XF, YV> (XF: 0 pairs, 1 plain fp32, 2 transformed-domain input; rounds 4-5: a bool); the product's 16-row launches
+    # are winox_kernel_tail<M, NH, NTW, XF, YV> (an 8-row body or folded tiles for a short last band)
+    xin = {"0": "", "false": "", "1": "[f32 in]", "true": "[f32 in]", "2": "[V in]", None: ""}
+    m = re.search(r"winox_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)(?:, (\d|true|false))?(?:, (true|false))?>", name)
     if m:
         return "winox_kernel<F(%s,3),%sx%s>[f16x3]" % m.groups()[:3] + ("[8 rows]" if m.group(4) == "2" else "") + ("[persistent]" if m.group(5) == "true" else "") + \
-               ("[f32 in]" if m.group(6) == "true" else "")
-    m = re.search(r"winox_kernel_tail<(\d+), (\d+), (\d+), (true|false)>", name)      # the product's 16-row tile launches (an 8-row body for a short last band)
+               xin[m.group(6)] + ("[V out]" if m.group(7) == "true" else "")
+    m = re.search(r"winox_kernel_tail<(\d+), (\d+), (\d+), (\d|true|false)(?:, (true|false))?>", name)
     if m:
-        return "winox_kernel<F(%s,3),%sx%s>[f16x3]" % m.groups()[:3] + ("[f32 in]" if m.group(4) == "true" else "")
+        return "winox_kernel<F(%s,3),%sx%s>[f16x3]" % m.groups()[:3] + xin[m.group(4)] + ("[V out]" if m.group(5) == "true" else "")
     m = re.search(r"wino_kernel<(\d+)>", name)
     if m:
         return "wino_kernel<F(%s,3)>[f16x3]" % m.group(1)
