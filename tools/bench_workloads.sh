@@ -10,7 +10,7 @@ run() {   # name, bench args...
   python $R/bench.py "$@" > $OUT/${TAG}_$name.json 2> $OUT/${TAG}_$name.err
   echo "$name rc=$? $(python -c "import json,sys; d=json.load(open('$OUT/${TAG}_$name.json')); print('%.1f frames/s, dominant %s %.0f TF (frac %.3f), parity %.1e' % (d['value'], d['roofline']['kernel'], d['roofline']['achieved'], d['roofline']['frac'], d['parity']['max_abs_f16x3_vs_exact_fp32_on_this_clip']))" 2>&1 | tail -1)"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_$name -o bench -- \
-     python $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-power-probe > /dev/null 2> $OUT/prof_${TAG}_$name.log
+     python $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-power-probe --no-box-calibration > /dev/null 2> $OUT/prof_${TAG}_$name.log
   f=$(find $OUT/prof_${TAG}_$name -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/${TAG}_${name}_kernel_stats.csv
   rm -rf $OUT/prof_${TAG}_$name

@@ -9,6 +9,6 @@ i=0
 for set in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pass$i -o pmc -- \
-     python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-power-probe ${BENCH_ARGS} > $OUT/pass$i.log 2>&1
+     python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-power-probe --no-box-calibration ${BENCH_ARGS} > $OUT/pass$i.log 2>&1
   echo "pass $i ($set): rc=$?"
 done
