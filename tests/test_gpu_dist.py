@@ -27,7 +27,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, outdir, precision):
+def _worker(rank, world, port, outdir, precision, kw=None):
     for p in (os.path.dirname(HERE), HERE, os.path.join(HERE, "golden")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -39,7 +39,7 @@ def _worker(rank, world, port, outdir, precision):
     from bsvd_amd.dist import HaloExchanger, shard_range
     st = seeded_state(bsvd_keys([64, 128, 256], 64, 4, 3, 64), 41)
     m = bsvd_amd.BSVD(chns=[64, 128, 256], mid_ch=64, norm="none", act="relu6", interm_ch=64, pretrain_ckpt=None,
-                      precision=precision)
+                      precision=precision, **(kw or {}))
     m.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
     m = m.cuda()
     x = torch.from_numpy(seeded_clip((1, 7, 4, 32, 48), 42, kind="sigma30"))[0].cuda()
@@ -62,6 +62,16 @@ def test_two_process_sharding_on_one_gpu(tmp_path, precision):
     y = np.concatenate([np.load(tmp_path / ("out%d.npy" % r)) for r in range(world)])
     whole = np.load(tmp_path / "whole.npy")
     assert y.shape == whole.shape == (7, 3, 32, 48)
+    assert np.array_equal(y, whole), "sharded == unsharded bit for bit (max diff %g)" % np.abs(y - whole).max()
+
+
+def test_two_process_sharding_with_transformed_domain_halos(tmp_path):
+    """the same two real processes with F(6,3) layers handing their tensors over in the transformed domain (engine.VT): the halo slices that travel
+    between the ranks are block slices of transformed frames (HaloExchanger packs, stages and receives them through the executor)"""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "f16x3", dict(wide_conv="wino6", v_handover=True)), nprocs=world, join=True)
+    y = np.concatenate([np.load(tmp_path / ("out%d.npy" % r)) for r in range(world)])
+    whole = np.load(tmp_path / "whole.npy")
     assert np.array_equal(y, whole), "sharded == unsharded bit for bit (max diff %g)" % np.abs(y - whole).max()
 
 
