@@ -416,11 +416,65 @@ static void case_fused_pair() {
     if (bsvd_conv3x3(&af, nullptr) != -20 || !strstr(bsvd_last_error(), "fold")) { printf("pre_w_packed + fold not refused\n"); ++failures; }
 }
 
+// case 10  two temporal-fusion convs 128 -> 128 -> 128 (MemCvBlock, bsvd_arch.py:116-149) as F(6,3) layers with the tensor BETWEEN them in the transformed
+// domain (ABI v11: the first launch writes y_v -- its epilogue applies the second layer's input transform, the patch pass completes the tile edges --, the
+// second reads x_v): against the plain-C oracle's two convs, and bit for bit against the same chain with a plain-fp32 tensor between the layers.
+static void case_transformed_handover() {
+    const int T = 2, C = 128, H = 19, W = 100, fold = C / 8;        // three 48-pixel tiles per row: two interior tile boundaries to patch
+    auto x = randv((size_t)T * C * H * W, 1.f), w1 = randv((size_t)C * C * 9, 0.04f), b1 = randv(C, 0.1f), w2 = randv((size_t)C * C * 9, 0.04f), b2 = randv(C, 0.1f);
+    auto xn = to_nhwc(x, T, C, H, W, C);                              // plain fp32 input of the first layer (x_f32)
+    float *dx = dev(xn), *dw1 = dev(w1), *db1 = dev(b1), *dw2 = dev(w2), *db2 = dev(b2);
+    float *wq1 = dev_zeros((size_t)bsvd_packed_wino_weight_elems(C, C, 6)), *bq1 = dev_zeros(C), *wq2 = dev_zeros((size_t)bsvd_packed_wino_weight_elems(C, C, 6)), *bq2 = dev_zeros(C);
+    ABI_OK(bsvd_pack_weights_wino(dw1, db1, C, C, C, C, 0, 6, wq1, bq1, nullptr));
+    ABI_OK(bsvd_pack_weights_wino(dw2, db2, C, C, C, C, 0, 6, wq2, bq2, nullptr));
+    const int64_t vfe = bsvd_v_frame_elems(H, W, C, 6);
+    if (vfe <= 0 || bsvd_v_groups(W, 6) != 24) { printf("bsvd_v_frame_elems / bsvd_v_groups\n"); ++failures; return; }
+    float *dv = dev_zeros((size_t)T * vfe), *dm = dev_zeros((size_t)T * H * W * C), *dy_v = dev_zeros((size_t)T * H * W * C), *dy_f = dev_zeros((size_t)T * H * W * C);
+    auto layer = [&](const float *in, int in_v, int in_f32, int64_t in_fs, float *wq, float *bq, float *out, int out_v, int out_f32, int64_t out_fs, const char *tag) {
+        BsvdConvArgs a; memset(&a, 0, sizeof(a));
+        a.x = in; a.x_frame_stride = in_fs; a.x_v = in_v; a.x_f32 = in_f32; a.fold = fold;       // no halos: zeros past both ends of the clip
+        a.w_wino_packed = wq; a.wino_m = 6; a.bias_packed = bq; a.y = out; a.y_frame_stride = out_fs; a.y_v = out_v; a.y_f32 = out_f32;
+        a.frames = T; a.H = H; a.W = W; a.Cin = C; a.Cout = C; a.stride = 1; a.act = BSVD_ACT_RELU6; a.epilogue = BSVD_EPI_PLAIN; a.dtype = BSVD_F16X3;
+        char name[96]; ABI_OK(bsvd_conv3x3_variant(&a, name, sizeof(name)));
+        if (!strstr(name, tag)) { printf("variant %s (expected %s)\n", name, tag); ++failures; }
+        ABI_OK(bsvd_conv3x3(&a, nullptr));
+    };
+    const int64_t fs = (int64_t)H * W * C;
+    layer(dx, 0, 1, fs, wq1, bq1, dv, 6, 0, vfe, "[V out]");            // transformed tensor between the layers
+    layer(dv, 6, 0, vfe, wq2, bq2, dy_v, 0, 0, fs, "[V in]");
+    layer(dx, 0, 1, fs, wq1, bq1, dm, 0, 1, fs, "[f32 in]");             // plain-fp32 tensor between the layers
+    layer(dm, 0, 1, fs, wq2, bq2, dy_f, 0, 0, fs, "[f32 in]");
+    HIP_OK(hipDeviceSynchronize());
+    auto gv = host(dy_v, (size_t)T * H * W * C), gf = host(dy_f, (size_t)T * H * W * C);
+    auto got = to_nchw(from_split16(gv), T, C, H, W, C);
+    std::vector<float> mid((size_t)T * C * H * W), want((size_t)T * C * H * W);
+    const size_t fr = (size_t)C * H * W, pl = (size_t)H * W;
+    std::vector<float> zeros(fr, 0.f);
+    for (int pass = 0; pass < 2; ++pass) {
+        const std::vector<float> &in = pass ? mid : x; std::vector<float> &out = pass ? want : mid;
+        for (int t = 0; t < T; ++t) {
+            const float *pv = (t == 0 ? zeros.data() : in.data() + (t - 1) * fr) + (t == 0 ? 0 : fold * pl);
+            const float *nx = (t == T - 1 ? zeros.data() : in.data() + (t + 1) * fr);
+            if (oracle_conv3x3(in.data() + t * fr, pv, nx, fold, pass ? w2.data() : w1.data(), pass ? b2.data() : b1.data(), C, C, H, W, 1, 2, 0, nullptr, out.data() + t * fr)) exit(4);
+        }
+    }
+    report("MemCvBlock 128->128->128 as F(6,3) layers, transformed-domain tensor between them (y_v -> x_v)", maxabs(got, want), 3e-4);
+    // the two chains differ only at the patched positions (one fp32 rounding later): their outputs agree to the last bits
+    report("... against the same chain with a plain-fp32 tensor between the layers", maxabs(got, to_nchw(from_split16(gf), T, C, H, W, C)), 2e-5);
+    // refusals: y_v needs the frame stride of a transformed frame; x_v of another form
+    BsvdConvArgs a; memset(&a, 0, sizeof(a));
+    a.x = dx; a.x_frame_stride = fs; a.x_f32 = 1; a.w_wino_packed = wq1; a.wino_m = 6; a.bias_packed = bq1; a.y = dv; a.y_frame_stride = fs; a.y_v = 6;
+    a.frames = T; a.H = H; a.W = W; a.Cin = C; a.Cout = C; a.stride = 1; a.act = BSVD_ACT_RELU6; a.dtype = BSVD_F16X3;
+    if (bsvd_conv3x3(&a, nullptr) != -22 || !strstr(bsvd_last_error(), "y_frame_stride")) { printf("short y_frame_stride not refused\n"); ++failures; }
+    a.y_frame_stride = vfe; a.x_f32 = 0; a.x_v = 2;
+    if (bsvd_conv3x3(&a, nullptr) != -22) { printf("x_v of another form not refused\n"); ++failures; }
+}
+
 int main() {
     if (bsvd_abi_version() != BSVD_ABI_VERSION || bsvd_conv_args_size() != (int)sizeof(BsvdConvArgs)) { printf("ABI mismatch\n"); return 1; }
     int n = 0; HIP_OK(hipGetDeviceCount(&n)); if (n < 1) { printf("no HIP device\n"); return 1; }
     HIP_OK(hipSetDevice(0));
-    case_tsm(); case_stride2(); case_pixel_shuffle(); case_split_chain(); case_fused_entry(); case_batch_and_graph(); case_stream_ring_graphs(); case_winograd(); case_fused_pair();
+    case_tsm(); case_stride2(); case_pixel_shuffle(); case_split_chain(); case_fused_entry(); case_batch_and_graph(); case_stream_ring_graphs(); case_winograd(); case_fused_pair(); case_transformed_handover();
     printf(failures ? "abi_parity: %d FAILED\n" : "abi_parity: all cases ok\n", failures);
     return failures ? 1 : 0;
 }
