@@ -86,8 +86,8 @@ _SOLE_CONSUMER = {"down0": "d0c1", "d0c1": "d0c2", "down1": "d1c1", "d1c1": "d1c
 # epilogue applies the consumer's input transform once and stores the tensor as V planes; the consumer's K loop is a 16-byte copy.  Takes
 # precedence over the plain-fp32 hand-over for the pairs it covers (the others -- stride-2 and PixelShuffle producers -- keep fp32).
 # OFF by default: built, bit-identical to the consumer transforming plain fp32 itself, and measured (profiles/r06b .. r06e): the consumer gains
-# 8-11 % per layer, the producer's epilogue (BT + 4 / 3 of the bytes, nothing to hide behind at one workgroup per CU) and the patch pass cost
-# 9-16 %: the C1 clip does not move (wino6: 384-390 frames/s without, 382-388 with the hand-over; wino2, the default form: 383-384).
+# 4-11 % per layer (layout-dependent), the producer's epilogue (BT + 4 / 3 of the bytes, nothing to hide behind at one workgroup per CU) and the patch pass cost
+# 7-16 %: the C1 clip does not move (wino6: 384-390 frames/s without, 382-388 with the hand-over; wino2, the default form: 383-384).
 V_HANDOVER_DEFAULT = False
 V_FORM = 6              # the form whose epilogue writes V (conv3x3_winox.hip: launch_winox_cfg)
 
