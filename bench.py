@@ -390,6 +390,17 @@ BOX_CAL_REF = {"direct64_ms": 1.000, "wino256_ms": 0.631,
                          "driver box: direct64 1.038, C1 366.0; the r06 session-1 box: 1.047, C1 366.8 (profiles/r06_box_calibration.json)"}
 
 
+def kernel_sources_sha16():
+    """sha256 (16 hex digits) over the kernel sources + the ABI header of this tree -- what profiles/traffic.json records for the tree its PMC passes ran on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "bsvd_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "bsvd_amd", "csrc", "*.h")) + [os.path.join(ROOT, "include", "bsvd_hip.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def normalise_value(value, cal_ms, ref_ms):
     """frames/s this run would show on the reference box: a box whose fixed calibration layer takes cal_ms where the reference box takes
     ref_ms is cal_ms / ref_ms slower, and throughput scales with the inverse.  None when either figure is missing."""
@@ -671,9 +682,11 @@ def main():
         peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_F16_MFMA_TFLOPS
         dom = max(agg, key=lambda k: agg[k]["ms"])
         ach = agg[dom]["flop"] / (agg[dom]["ms"] * 1e-3) / 1e12
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_match = None, None, None
         try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/make_traffic.py)
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            # the table is a committed file: say whether the kernel sources it was collected on are the ones this line runs
+            traffic_match = (tj.get("sources_sha16") == kernel_sources_sha16()) if tj.get("sources_sha16") else None
             if args.workload == "c1" and mode == "clip" and frames == 10:      # the table was collected on this workload
                 traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
                 traffic_src = "profiles/traffic.json (%s; %s)" % (tj["source"], tj["formula"])
@@ -682,7 +695,7 @@ def main():
         traffic_alg = agg[dom]["bytes"] / agg[dom]["launches"]
         return {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, separate passes)",
-                "traffic_source": traffic_src,
+                "traffic_source": traffic_src, "traffic_sources_match": traffic_match,
                 # the least a launch of this kernel has to move (inputs, outputs, skip / residual operand and weights once each, averaged
                 # over the kernel's launches of this step) and what it moves relative to that: > 1 = re-reads
                 "traffic_algorithmic": traffic_alg, "traffic_ratio": (traffic / traffic_alg) if traffic else None,

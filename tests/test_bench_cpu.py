@@ -81,3 +81,14 @@ def test_value_normalised_arithmetic():
     for cal, ref in ((None, 1.0), (1.0, None), (0.0, 1.0), (1.0, 0.0)):
         assert bench.normalise_value(366.0, cal, ref) is None
     assert set(bench.BOX_CAL_REF) >= {"direct64_ms", "wino256_ms", "source"} and bench.BOX_CAL_REF["direct64_ms"] > 0
+
+
+def test_committed_traffic_table_was_collected_on_these_kernel_sources():
+    """roofline.traffic is read from the committed profiles/traffic.json (PMC passes cannot run inside bench.py): the table names the
+    kernel sources it was collected on, bench.py compares (roofline.traffic_sources_match), and this test keeps the committed pair in step --
+    a kernel change without a new PMC session fails here instead of silently quoting stale bytes (VERDICT r05 weak #8)."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert t.get("sources_sha16") == bench.kernel_sources_sha16(), "kernel sources changed since profiles/traffic.json was collected: re-run tools/pmc_run.sh + make_traffic.py"
