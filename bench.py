@@ -391,13 +391,18 @@ BOX_CAL_REF = {"direct64_ms": 1.000, "wino256_ms": 0.631,
 
 
 def kernel_sources_sha16():
-    """sha256 (16 hex digits) over the kernel sources + the ABI header of this tree -- what profiles/traffic.json records for the tree its PMC passes ran on"""
+    """sha256 (16 hex digits) over the kernel sources + the ABI header of this tree, `//` comments and blank space stripped (a reworded comment is not a new
+    kernel) -- what profiles/traffic.json records for the tree its PMC passes ran on"""
     import glob
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "bsvd_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "bsvd_amd", "csrc", "*.h")) + [os.path.join(ROOT, "include", "bsvd_hip.h")]):
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        for line in open(f, "r", errors="replace"):
+            line = re.sub(r"\s+", " ", re.sub(r"//.*$", "", line)).strip()
+            if line:
+                h.update(line.encode())
     return h.hexdigest()[:16]
 
 

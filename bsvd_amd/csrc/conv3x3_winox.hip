@@ -276,6 +276,9 @@ __device__ __forceinline__ void winox_tile(const ConvParams &p)
         if (p.flip) lid = ntiles - 1 - lid;
         const int f = lid / G.per_frame;
         int r = lid - f * G.per_frame, ct, tx, ty;
+        // (channel tile FASTEST: the channel tiles of a pixel tile are concurrent neighbours on one XCD and its input is read once.  Channel tile slowest within a
+        //  frame -- an XCD on ONE channel tile's U at a time; the 6.3 MB of U of the 256 -> 512 layer do not fit a 4 MB L2 -- measures 2-3 % slower for F(2,3),
+        //  6-8 % for F(6,3): profiles/r06h_tile_order_ct_outer_*.txt)
         if (FG != 0 && G.fold && r >= G.nreg) { r -= G.nreg; ct = r % p.nct; tx = 2 * (r / p.nct); ty = p.nty - 1; }
         else { ct = r % p.nct; r /= p.nct; tx = r % p.ntx; ty = r / p.ntx; }
         t.f = f; t.oy0 = ty * GTR; t.ox0 = tx * C::TWPX; t.n0 = ct * C::BN;

@@ -60,13 +60,10 @@ for k, v in agg.items():
     fetch = v["FETCH_SIZE"] / max(nf, 1) * 1024.0
     write = v["WRITE_SIZE"] / max(nw, 1) * 1024.0
     res[k] = {"launches_sampled": nf, "fetch_bytes_raw": fetch, "write_bytes": write, "hbm_bytes_per_launch": 2 * fetch + write}
-import hashlib
-_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_h = hashlib.sha256()
-for _f in sorted(glob.glob(os.path.join(_root, "bsvd_amd", "csrc", "*.hip")) + glob.glob(os.path.join(_root, "bsvd_amd", "csrc", "*.h")) + [os.path.join(_root, "include", "bsvd_hip.h")]):
-    _h.update(os.path.basename(_f).encode()); _h.update(open(_f, "rb").read())
-json.dump({"source": os.path.basename(d.rstrip("/")), "sources_sha16": _h.hexdigest()[:16],
-           "sources_sha16_note": "sha256 over bsvd_amd/csrc/*.hip, *.h and include/bsvd_hip.h of the tree the PMC passes ran on (bench.py compares it with the tree it runs from: roofline.traffic_sources_match)",
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as _bench                      # one definition of the hash: bench.kernel_sources_sha16
+json.dump({"source": os.path.basename(d.rstrip("/")), "sources_sha16": _bench.kernel_sources_sha16(),
+           "sources_sha16_note": "sha256 over bsvd_amd/csrc/*.hip, *.h and include/bsvd_hip.h (comments stripped) of the tree the PMC passes ran on (bench.py compares it with the tree it runs from: roofline.traffic_sources_match)",
            "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch",
            "calibration": "profiles/traffic_calibration.json: every memory-side read request is a 128-B line fill tallied at 64 B "
                           "(stream 2.000; conv patch pattern: same factor, 1.08-1.11x the tensor in lines)",
