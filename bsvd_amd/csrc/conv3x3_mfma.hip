@@ -1553,6 +1553,11 @@ int launch_conv3x3(const ConvParams &p, int stride, hipStream_t stream, char *na
             // (r06f_stride2_timeline.txt) -- and the 32-channel wave tile pulls half the weight bytes per MFMA through the L1 (twice the pixel-fragment
             // reads from LDS): 2.32 -> 2.21 ms per C1 clip for the four launches, same bits (r06g_stride2_variants*.txt).  Refuted before: memory-side
             // re-fetches (r04), LDS bank conflicts (r05), and in round 6 the item decode at the chunk boundaries (a map with one v_add per item: +1 %).
+            // (Small grids: the 64 -> 128 layer on ONE 540 x 960 frame is 1020 workgroups on 768 slots -- two rounds for 1.33 rounds of work.  The same tile with 64
+            //  channels per workgroup (<2,1,2,2,2>: twice the workgroups at half the size, same bits) is SLOWER, 0.0640 -> 0.0670 ms, per-frame API 359.7 -> 357.7
+            //  frames/s: a workgroup with half the MFMAs pays the same prologue and epilogue.  profiles/r06k_stride2_small_grid_*.txt)
+            // (tools/kernel_resources.sh shows a 68-byte private segment for <4,1,1,4,2>: a reservation only -- the kernel's ISA contains no scratch, flat-scratch or
+            //  private buffer instruction; 154 VGPRs, three workgroups per CU)
             return launch_cfg<ConvCfg<4, 1, 1, 4, 2, 3, false>, true, 1>(p, stream, name, name_len);
         }
         // The fat tiles run one workgroup per CU, so they need a grid of several rounds of 256; small launches
